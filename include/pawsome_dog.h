@@ -1,0 +1,130 @@
+/*
+ * pawsome_dog.h — C ABI of the MI355X-native DoG + argmax hot path.
+ *
+ * This is the drop-in boundary for PawsomeTracker's `Tracker`
+ * (reference: /root/reference/src/PawsomeTracker.jl).  The reference has no
+ * FFI of its own; the seam is the Julia callable-struct protocol
+ *     Tracker(img, target_width, window_size, darker_target)   :39-52
+ *     trckr(guess::NTuple{2,Int})::NTuple{2,Int}               :55-62
+ *     read!(vid, trckr.img.data)  (frame ingest, in place)     :166
+ * A Julia shim keeps those three spellings and `ccall`s the
+ * entry points below.  Plain pointers and sizes only; every call returns an
+ * int status (0 = ok) and never throws or aborts across the boundary;
+ * pdog_last_error() gives the text the shim turns into `error(...)`.
+ *
+ * Conventions (all follow the reference):
+ *  - frames are raw GRAY8, row-major h x w (what the PermutedDimsArray at
+ *    :36 wraps), value = raw/255 (Gray{N0f8});
+ *  - positions are 1-based (row, col) int32 pairs (CartesianIndex{2}, :173);
+ *  - window_size is (h, w) AFTER fix_window_size (:70-72); radii = size .÷ 2
+ *    (:44), so a window has 2r+1 rows/cols (:56);
+ *  - everything outside the frame reads as the fill value (PaddedView, :48).
+ *
+ * Threading: a tracker handle is single-caller, like a `Tracker` (shared
+ * buffers, :37); distinct handles may be used from distinct threads.
+ */
+#ifndef PAWSOME_DOG_H
+#define PAWSOME_DOG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDOG_ABI_VERSION 1
+
+enum pdog_status {
+    PDOG_OK = 0,
+    PDOG_E_ARG = 1,    /* bad argument (null pointer, non-positive size, ...) */
+    PDOG_E_HIP = 2,    /* a HIP runtime call failed; text in pdog_last_error() */
+    PDOG_E_NODEV = 3,  /* no usable gfx950 device */
+    PDOG_E_RANGE = 4,  /* a guess lies further outside the frame than the reference's pad allows */
+    PDOG_E_ALLOC = 5
+};
+
+typedef struct pdog_tracker pdog_tracker; /* opaque; replaces `struct Tracker`, :32-53 */
+
+/* Geometry the host side may want to read back (all derived as the reference derives them). */
+typedef struct pdog_info {
+    int32_t frame_h, frame_w; /* sz, :40 */
+    int32_t radius_h, radius_w; /* radii = window_size .÷ 2, :44 */
+    int32_t win_h, win_w;     /* 2r+1 per dim, :56 */
+    int32_t kernel_len;       /* l of Kernel.DoG(sigma), :43 */
+    int32_t fill;             /* mode of the first frame, :47 */
+    int32_t darker_target;    /* :42 */
+    int32_t n_strips;         /* column strips one window is split into on the GPU */
+    int32_t strip_w;          /* output columns per strip */
+    int32_t variant;          /* id of the compiled kernel specialisation in use */
+    double sigma;             /* get_sigma(target_width), :30 */
+    double target_width;
+    int64_t algorithmic_bytes_per_window; /* (win_h+l-1)*(win_w+l-1) u8 + 8 B out */
+    int64_t algorithmic_fma_per_window;   /* separable, both Gaussians, both passes */
+} pdog_info;
+
+int pdog_abi_version(void);
+/* Text of the last failure on the calling thread ("" if none). */
+const char *pdog_last_error(void);
+
+/* ---- scalar helpers (host arithmetic, Float64 like the reference) ---- */
+/* get_sigma, src/PawsomeTracker.jl:30 */
+double pdog_sigma(double target_width);
+/* guess_window_size, src/PawsomeTracker.jl:64-68 */
+int pdog_default_window(double target_width);
+/* length l of Kernel.DoG(get_sigma(target_width)), src/PawsomeTracker.jl:43 */
+int pdog_kernel_len(double target_width);
+/* The two normalised 1-D Gaussians whose outer products make Kernel.DoG (:43):
+ * which = 0 -> sigma, which = 1 -> sqrt(2) sigma.  out has room for cap doubles. */
+int pdog_gaussian_taps(double target_width, int which, double *out, int cap);
+/* mode(_img), src/PawsomeTracker.jl:47 (StatsBase.mode tie rule: first value whose
+ * count exceeds the running maximum while scanning column-major). Host pointer. */
+int pdog_mode_u8(const uint8_t *img, int h, int w, int64_t row_stride, int *out_mode);
+
+/* ---- Tracker constructor, src/PawsomeTracker.jl:39-52 ----
+ * win_h/win_w: window_size in (h, w) order; fill: the mode of the first frame
+ * (pdog_mode_u8), frozen for the tracker's life like :47.  device: HIP ordinal. */
+int pdog_create(int device, int frame_h, int frame_w, double target_width,
+                int win_h, int win_w, int darker_target, int fill, pdog_tracker **out);
+int pdog_destroy(pdog_tracker *t);
+int pdog_get_info(const pdog_tracker *t, pdog_info *out);
+int pdog_set_fill(pdog_tracker *t, int fill);
+/* Launch on this hipStream_t (NULL = the tracker's own stream, the default). */
+int pdog_set_stream(pdog_tracker *t, void *hip_stream);
+/* Pre-size the per-window workspace so pdog_detect_batch never allocates. */
+int pdog_reserve(pdog_tracker *t, int max_windows);
+/* Force a kernel specialisation (tuning/tests); -1 = automatic. */
+int pdog_set_variant(pdog_tracker *t, int variant);
+int pdog_sync(pdog_tracker *t);
+
+/* ---- the functor, src/PawsomeTracker.jl:55-62, n independent applications ----
+ * All pointers are DEVICE pointers.
+ *  d_frames      n_frames frames, frame k at d_frames + k*frame_stride, rows row_stride bytes apart
+ *  d_frame_index window b looks at frame d_frame_index[b]; NULL -> frame b
+ *  d_guesses     n x 2 int32, 1-based (row, col); need not be clamped (a6)
+ *  d_out_ij      n x 2 int32, 1-based (row, col), clamped to the frame (:61)
+ *  d_out_resp    NULL, or n x win_h x win_w float32, column-major per window: the
+ *                DoG response findmax sees (:58), for parity checks only
+ * Asynchronous on the tracker's stream. */
+int pdog_detect_batch(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
+                      int64_t row_stride, int n_frames, const int32_t *d_frame_index,
+                      const int32_t *d_guesses, int n, int32_t *d_out_ij, float *d_out_resp);
+
+/* One frame from HOST memory: ingest (:166) + functor (:167) + result back on
+ * the host.  Synchronous.  h_resp may be NULL.  This is what the Julia shim's
+ * `trckr(guess)` calls. Returns PDOG_E_RANGE where the reference would raise a
+ * BoundsError (guess more than l - l÷2 - 1 outside the frame). */
+int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride,
+                     const int32_t guess[2], int32_t out_ij[2], float *h_resp);
+
+/* The intended frame loop, src/PawsomeTracker.jl:163-169 (:167):
+ * out[0] = functor(frame 0, start_guess); out[k] = functor(frame k, out[k-1]).
+ * d_frames / d_out_ij are device pointers; start_guess is a host pointer. */
+int pdog_detect_chain(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
+                      int64_t row_stride, int n_frames, const int32_t start_guess[2],
+                      int32_t *d_out_ij);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAWSOME_DOG_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of include/pawsome_dog.h (the C-ABI drop-in boundary).
+
+The HIP extension is the product path: if libpawsome_dog.so is missing this
+module raises — there is no CPU fallback and nothing here touches oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpawsome_dog.so")
+
+PDOG_OK, PDOG_E_ARG, PDOG_E_HIP, PDOG_E_NODEV, PDOG_E_RANGE, PDOG_E_ALLOC = range(6)
+
+# every symbol include/pawsome_dog.h declares (tests check the library exports them all)
+SYMBOLS = (
+    "pdog_abi_version", "pdog_last_error", "pdog_sigma", "pdog_default_window", "pdog_kernel_len",
+    "pdog_gaussian_taps", "pdog_mode_u8", "pdog_create", "pdog_destroy", "pdog_get_info",
+    "pdog_set_fill", "pdog_set_stream", "pdog_reserve", "pdog_set_variant", "pdog_sync",
+    "pdog_detect_batch", "pdog_detect_host", "pdog_detect_chain",
+)
+
+
+class PdogInfo(C.Structure):
+    _fields_ = [
+        ("frame_h", C.c_int32), ("frame_w", C.c_int32),
+        ("radius_h", C.c_int32), ("radius_w", C.c_int32),
+        ("win_h", C.c_int32), ("win_w", C.c_int32),
+        ("kernel_len", C.c_int32), ("fill", C.c_int32), ("darker_target", C.c_int32),
+        ("n_strips", C.c_int32), ("strip_w", C.c_int32), ("variant", C.c_int32),
+        ("sigma", C.c_double), ("target_width", C.c_double),
+        ("algorithmic_bytes_per_window", C.c_int64), ("algorithmic_fma_per_window", C.c_int64),
+    ]
+
+
+class PdogError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pawsome_dog status {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    i, d, p, i64 = C.c_int, C.c_double, C.c_void_p, C.c_int64
+    L.pdog_abi_version.restype = i
+    L.pdog_last_error.restype = C.c_char_p
+    L.pdog_sigma.restype = d; L.pdog_sigma.argtypes = [d]
+    L.pdog_default_window.restype = i; L.pdog_default_window.argtypes = [d]
+    L.pdog_kernel_len.restype = i; L.pdog_kernel_len.argtypes = [d]
+    L.pdog_gaussian_taps.restype = i; L.pdog_gaussian_taps.argtypes = [d, i, p, i]
+    L.pdog_mode_u8.restype = i; L.pdog_mode_u8.argtypes = [p, i, i, i64, C.POINTER(i)]
+    L.pdog_create.restype = i; L.pdog_create.argtypes = [i, i, i, d, i, i, i, i, C.POINTER(p)]
+    L.pdog_destroy.restype = i; L.pdog_destroy.argtypes = [p]
+    L.pdog_get_info.restype = i; L.pdog_get_info.argtypes = [p, C.POINTER(PdogInfo)]
+    L.pdog_set_fill.restype = i; L.pdog_set_fill.argtypes = [p, i]
+    L.pdog_set_stream.restype = i; L.pdog_set_stream.argtypes = [p, p]
+    L.pdog_reserve.restype = i; L.pdog_reserve.argtypes = [p, i]
+    L.pdog_set_variant.restype = i; L.pdog_set_variant.argtypes = [p, i]
+    L.pdog_sync.restype = i; L.pdog_sync.argtypes = [p]
+    L.pdog_detect_batch.restype = i
+    L.pdog_detect_batch.argtypes = [p, p, i64, i64, i, p, p, i, p, p]
+    L.pdog_detect_host.restype = i; L.pdog_detect_host.argtypes = [p, p, i64, p, p, p]
+    L.pdog_detect_chain.restype = i; L.pdog_detect_chain.argtypes = [p, p, i64, i64, i, p, p]
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != PDOG_OK:
+        raise PdogError(code, lib().pdog_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,354 @@
+// dog_kernels.hpp — gfx950 (CDNA4) device code for the DoG + argmax hot path.
+//
+// Replaces, for a batch of independent search windows, the body of the
+// reference functor /root/reference/src/PawsomeTracker.jl:55-62:
+//   :57  imfilter!(…, kernel = ±Kernel.DoG(σ), NoPad(), window)   -> row pass + column pass
+//   :58-59 findmax(view(buff, window))                              -> fused argmax
+//   :60-61 index map + clamp                                        -> dog_finalize_kernel
+// and the PaddedView fill semantics of :48 (reads outside the frame = fill).
+//
+// Algorithm (not the reference's: ImageFiltering runs the rank-2 DoG as ONE
+// dense l×l Float64 kernel; here it is two separable Gaussians in FP32):
+//   v      = pixel − fill                       (exact integer, kills the DC term: ΣK = 0)
+//   R±[a,x]= Σ_k g±[k] · v[a, x+k]              row pass (contiguous direction)
+//   D[y,x] = Σ_k (s·g+[k])·R+[y+k,x] + (−s·g−[k])·R−[y+k,x],  s = ±1/255   column pass
+// One workgroup owns one column strip of one window and streams input rows
+// through LDS in chunks: stage (u8 → f32 tile) → row pass (P outputs per lane,
+// sliding register window) → ring of R rows in LDS → column pass (Q outputs
+// per lane, sliding register window) → running (max, first col-major index)
+// in registers → wave-shuffle + LDS reduction → one partial per strip.
+// Both Gaussians ride in one v_pk_fma_f32 (pairs), taps come from SGPRs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pdog {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+// Filter taps are read through the CONSTANT address space: a load from it with a
+// uniform address is always selected as a scalar load (s_load → SGPR operand).
+typedef const f2 __attribute__((address_space(4))) *tap_ptr;
+__device__ __forceinline__ tap_ptr as_taps(const f2 *p) { return (tap_ptr)(unsigned long long)p; }
+
+struct LaunchGeo {
+    const uint8_t *__restrict__ frames;
+    long long frame_stride, row_stride;
+    const int *__restrict__ frame_index; // may be null
+    const int *__restrict__ guesses;     // n x 2, 1-based (row, col)
+    float *__restrict__ resp;            // only written by RESP instantiations
+    float *__restrict__ part_val;        // n x nstrips
+    int *__restrict__ part_idx;          // n x nstrips
+    int fh, fw, r1, r2, n1, n2, L, fill, nstrips, n;
+    int RR, pitchA;                      // only read by runtime-L variants
+    int nblocks;                         // n * nstrips
+};
+
+__host__ __device__ constexpr int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// LDS row pitches.  A (f32 input tile) is read by lanes that sit in consecutive
+// rows (ds_read_b32, 32 banks): an odd pitch spreads them over all banks.
+__host__ __device__ constexpr int pitch_a(int cols) { return cols | 1; }
+// R ring (f2 per element) is written row-per-lane (ds_write_b64) and read
+// column-per-lane (ds_read_b64, conflict free for any pitch); pitch in f2 units
+// with 2*pitch ≡ 2 (mod 32) would be ideal for the writes; odd is a good compromise.
+__host__ __device__ constexpr int pitch_r(int tw) { return tw | 1; }
+__host__ __device__ constexpr int ring_rows(int CH, int L, int Q)
+{
+    // rows a col-pass span can touch: CH new + L-1 halo + (Q-1) slack when the
+    // chunk cadence leaves a partial Q-group behind; multiple of 4 for the wrap logic
+    return round_up(CH + L - 1 + (((CH % Q) == 0 && ((L - 1) % Q) == 0) ? 0 : Q - 1), 4);
+}
+
+__device__ __forceinline__ f2 fma_bcast(float a, f2 t, f2 c)
+{
+    f2 av = {a, a};
+    return __builtin_elementwise_fma(av, t, c);
+}
+__device__ __forceinline__ f2 fma_pair(f2 a, f2 t, f2 c) { return __builtin_elementwise_fma(a, t, c); }
+
+// acc[o] += Σ_{u<U} a[o+u] · taps[u]   (both Gaussians in the pair)
+template <int P, int U>
+__device__ __forceinline__ void row_block(f2 (&acc)[P], const float *a, tap_ptr taps)
+{
+    float in[P + U - 1];
+#pragma unroll
+    for (int i = 0; i < P + U - 1; ++i) in[i] = a[i];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const f2 t = taps[u];
+#pragma unroll
+        for (int o = 0; o < P; ++o) acc[o] = fma_bcast(in[o + u], t, acc[o]);
+    }
+}
+
+// Ring reader: row offset `ro` (from the lane's first row y0) → element.
+// The ring wraps at most once inside a span; slot0 and RR are multiples of WB
+// (4 or 8), so a WB-row block never straddles the wrap and one select serves WB reads.
+template <int WB>
+struct RingLane {
+    const f2 *pA, *pB;
+    int wblk; // WB-row blocks before the wrap
+    template <int PITCH>
+    __device__ __forceinline__ f2 rd(int ro) const
+    {
+        const f2 *base = ((ro / WB) < wblk) ? pA : pB;
+        return base[ro * PITCH];
+    }
+};
+
+template <int Q, int U, int PITCH, int WB>
+__device__ __forceinline__ void col_block(f2 (&acc)[Q], const RingLane<WB> &rl, int k0, tap_ptr taps)
+{
+    f2 in[Q + U - 1];
+#pragma unroll
+    for (int i = 0; i < Q + U - 1; ++i) in[i] = rl.template rd<PITCH>(k0 + i);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const f2 t = taps[k0 + u];
+#pragma unroll
+        for (int o = 0; o < Q; ++o) acc[o] = fma_pair(in[o + u], t, acc[o]);
+    }
+}
+
+// Compile-time-length FIR with a sliding register window, in tap blocks of U:
+//   acc[o] += Σ_{u<L} ld(o+u) · taps[u],  o < NOUT
+// Per block: U taps come in by scalar loads (SGPR operands), the next block's U
+// inputs are requested from LDS before this block's NOUT·U packed FMAs run, and a
+// scheduling barrier closes the block so that neither the SGPR nor the VGPR live
+// ranges of later blocks are pulled forward (the unconstrained schedule keeps all
+// L taps live and spills SGPRs through v_readlane).  Every output sees the taps in
+// the same order u = 0..L-1, so equal inputs give bit-equal outputs (flat windows
+// must tie exactly, like the reference's identical per-pixel loops).
+template <int NOUT, int L, int U, typename T, typename Loader, typename Fma>
+__device__ __forceinline__ void fir_sliding(f2 (&acc)[NOUT], Loader ld, Fma fma, tap_ptr taps)
+{
+    constexpr int NB = (L + U - 1) / U;
+    T win[NOUT - 1 + U];
+    T nxt[U];
+    f2 tn[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+        if (j < L) tn[j] = taps[j];
+#pragma unroll
+    for (int i = 0; i < NOUT - 1; ++i) win[i] = ld(i);
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+        if (j < L) nxt[j] = ld(NOUT - 1 + j);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int u0 = b * U;
+        const int nu = (L - u0) < U ? (L - u0) : U;
+        f2 t[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+            if (j < nu) { win[NOUT - 1 + j] = nxt[j]; t[j] = tn[j]; }
+        // requests for the next block go out before this block's FMAs
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+            if (u0 + U + j < L) { tn[j] = taps[u0 + U + j]; nxt[j] = ld(NOUT - 1 + u0 + U + j); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (u < nu) {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) acc[o] = fma(win[o + u], t[u], acc[o]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NOUT - 1; ++i) win[i] = win[i + nu];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Hide a uniform pointer from loop-invariant code motion (keeps it in SGPRs).
+__device__ __forceinline__ tap_ptr opaque_uniform(const f2 *p)
+{
+    unsigned long long u = (unsigned long long)p;
+    asm volatile("" : "+s"(u));
+    return (tap_ptr)u;
+}
+
+// P outputs/lane in the row pass, XG lane-groups across the strip (strip width
+// TW = P*XG), Q outputs/lane in the column pass, CH input rows per chunk,
+// LT = compile-time kernel length (0: runtime L), NT threads.
+// taps_row: L pairs (g+[k], g−[k]); taps_col: L pairs (s·g+[k], −s·g−[k]).  They are
+// top-level __restrict__ kernel arguments so that the uniform tap loads become scalar
+// (s_load → SGPR operands of v_pk_fma_f32) instead of per-lane vector loads.
+template <int P, int XG, int Q, int CH, int LT, int NT, bool RESP>
+__global__ __launch_bounds__(NT, 2) void dog_window_kernel(const LaunchGeo g, const f2 *__restrict__ taps_row,
+                                                           const f2 *__restrict__ taps_col)
+{
+    constexpr int TW = P * XG;
+    constexpr int PR = pitch_r(TW);
+    constexpr int NW = NT / 64;
+    static_assert(CH % 4 == 0 && Q % 4 == 0, "wrap logic works on 4-row blocks");
+    // 8-row wrap blocks when every y0 and the ring length are multiples of 8
+    constexpr int WB = (LT && CH % 8 == 0 && Q % 8 == 0 && ring_rows(CH, LT ? LT : 1, Q) % 8 == 0) ? 8 : 4;
+    const int L = LT ? LT : g.L;
+    const int hw = L >> 1;
+    const int TWin = TW + L - 1;
+    const int PA = LT ? pitch_a(TW + LT - 1) : g.pitchA;
+    const int RR = LT ? ring_rows(CH, LT, Q) : g.RR;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *A = reinterpret_cast<float *>(smem);
+    f2 *ring = reinterpret_cast<f2 *>(smem + round_up(CH * PA * 4, 16));
+
+    // XCD-aware block → (window, strip): blocks are dealt round-robin over the 8
+    // XCDs, so give each XCD a contiguous range of logical ids; the strips of one
+    // window (which share their halo columns) then meet in one L2.  Speed only.
+    const int per_xcd = (g.nblocks + 7) >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= g.nblocks) return;
+    const int b = logical / g.nstrips;
+    const int s = logical - b * g.nstrips;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
+    const int fidx = g.frame_index ? g.frame_index[b] : b;
+    const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
+    const int x0 = s * TW;                 // first window column of this strip
+    const int ti0 = g1 - g.r1 - 1 - hw;    // 0-based frame row of input row 0
+    const int tj0 = g2 - g.r2 - 1 + x0 - hw; // 0-based frame col of input col 0
+    const int NA = g.n1 + L - 1;           // input rows
+    const int ws = min(TW, g.n2 - x0);     // valid output columns in this strip
+
+    float best = -__builtin_huge_valf();
+    int best_idx = 0x7fffffff;
+    int y_done = 0;
+
+    for (int c0 = 0; c0 < NA; c0 += CH) {
+        // ---- stage: rows [c0, c0+CH) × cols [0, TWin) as f32 (pixel − fill) ----
+        for (int r = wave; r < CH; r += NW) {
+            const int a = c0 + r, gi = ti0 + a;
+            const bool rowok = (a < NA) && (gi >= 0) && (gi < g.fh);
+            const uint8_t *src = frame + (long long)gi * g.row_stride;
+            for (int c = lane; c < TWin; c += 64) {
+                const int gj = tj0 + c;
+                int v = g.fill;
+                if (rowok && gj >= 0 && gj < g.fw) v = src[gj];
+                A[r * PA + c] = (float)(v - g.fill);
+            }
+        }
+        __syncthreads();
+        // ---- row pass: task = (row r, lane-group gx), r fastest ----
+        for (int t = tid; t < CH * XG; t += NT) {
+            const int r = t % CH, gx = t / CH;
+            const float *a = A + r * PA + gx * P;
+            f2 acc[P];
+#pragma unroll
+            for (int o = 0; o < P; ++o) acc[o] = f2{0.f, 0.f};
+            if (LT) {
+                fir_sliding<P, (LT ? LT : 1), 8, float>(
+                    acc, [&](int i) { return a[i]; },
+                    [](float v, f2 t, f2 c) { return fma_bcast(v, t, c); }, opaque_uniform(taps_row));
+            } else {
+                int k0 = 0;
+                for (; k0 + 16 <= L; k0 += 16) row_block<P, 16>(acc, a + k0, as_taps(taps_row) + k0);
+                for (; k0 + 4 <= L; k0 += 4) row_block<P, 4>(acc, a + k0, as_taps(taps_row) + k0);
+                for (; k0 < L; ++k0) row_block<P, 1>(acc, a + k0, as_taps(taps_row) + k0);
+            }
+            f2 *dst = ring + ((c0 + r) % RR) * PR + gx * P;
+#pragma unroll
+            for (int o = 0; o < P; ++o) dst[o] = acc[o];
+        }
+        __syncthreads();
+        // ---- column pass over the output rows that became computable ----
+        const bool last = (c0 + CH >= NA);
+        const int y_avail = last ? g.n1 : (c0 + CH - (L - 1));
+        if (y_avail > y_done) {
+            const int y_hi = last ? y_avail : (y_done + (y_avail - y_done) / Q * Q);
+            const int ngrp = (y_hi - y_done + Q - 1) / Q;
+            for (int t = tid; t < ngrp * TW; t += NT) {
+                const int yg = t / TW, x = t - yg * TW;
+                const int y0 = y_done + yg * Q;
+                const int slot0 = y0 % RR;
+                RingLane<WB> rl;
+                rl.pA = ring + slot0 * PR + x;
+                rl.pB = rl.pA - RR * PR;
+                rl.wblk = (RR - slot0) / WB;
+                f2 acc[Q];
+#pragma unroll
+                for (int o = 0; o < Q; ++o) acc[o] = f2{0.f, 0.f};
+                if (LT) {
+                    fir_sliding<Q, (LT ? LT : 1), 8, f2>(
+                        acc, [&](int ro) { return rl.template rd<PR>(ro); },
+                        [](f2 v, f2 t, f2 c) { return fma_pair(v, t, c); }, opaque_uniform(taps_col));
+                } else {
+                    int k0 = 0;
+                    for (; k0 + 16 <= L; k0 += 16) col_block<Q, 16, PR>(acc, rl, k0, as_taps(taps_col));
+                    for (; k0 + 4 <= L; k0 += 4) col_block<Q, 4, PR>(acc, rl, k0, as_taps(taps_col));
+                    for (; k0 < L; ++k0) col_block<Q, 1, PR>(acc, rl, k0, as_taps(taps_col));
+                }
+                {
+                    const int lin0 = (x0 + x) * g.n1 + y0; // column-major index in the window
+                    const bool colok = x < ws;
+                    const int nvalid = colok ? (y_hi - y0) : 0; // outputs o < nvalid count
+                    float v[Q];
+                    float m = -__builtin_huge_valf();
+#pragma unroll
+                    for (int o = 0; o < Q; ++o) {
+                        v[o] = acc[o].x + acc[o].y;
+                        if (RESP && o < nvalid) g.resp[(long long)b * g.n1 * g.n2 + lin0 + o] = v[o];
+                        v[o] = (o < nvalid) ? v[o] : -__builtin_huge_valf();
+                        m = fmaxf(m, v[o]);
+                    }
+                    // first maximum in column-major order (findmax, :59); the index search only
+                    // runs for a lane whose group reaches its running maximum (rare after warm-up)
+                    if (m >= best && nvalid > 0) {
+#pragma unroll
+                        for (int o = 0; o < Q; ++o)
+                            if (v[o] > best || (v[o] == best && lin0 + o < best_idx)) { best = v[o]; best_idx = lin0 + o; }
+                    }
+                }
+            }
+            y_done = y_hi;
+        }
+        __syncthreads();
+    }
+
+    // ---- peak: wave shuffle reduction, then across waves through LDS ----
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_down(best, off, 64);
+        const int oi = __shfl_down(best_idx, off, 64);
+        if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
+    }
+    float *sval = reinterpret_cast<float *>(smem);
+    int *sidx = reinterpret_cast<int *>(smem + 64);
+    if (lane == 0) { sval[wave] = best; sidx[wave] = best_idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < NW; ++w) {
+            const float ov = sval[w];
+            const int oi = sidx[w];
+            if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
+        }
+        g.part_val[logical] = best;
+        g.part_idx[logical] = best_idx;
+    }
+}
+
+// Combine the strips of each window, map window-local → absolute, clamp
+// (src/PawsomeTracker.jl:60-61).  One thread per window.
+__global__ void dog_finalize_kernel(const float *__restrict__ part_val, const int *__restrict__ part_idx,
+                                    const int *__restrict__ guesses, int *__restrict__ out_ij,
+                                    int n, int nstrips, int r1, int r2, int n1, int fh, int fw)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    float best = part_val[b * nstrips];
+    int idx = part_idx[b * nstrips];
+    for (int s = 1; s < nstrips; ++s) {
+        const float v = part_val[b * nstrips + s];
+        const int i = part_idx[b * nstrips + s];
+        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+    }
+    const int x = idx / n1, y = idx - x * n1;
+    int i = guesses[2 * b] - r1 + y;
+    int j = guesses[2 * b + 1] - r2 + x;
+    i = min(max(i, 1), fh);
+    j = min(max(j, 1), fw);
+    out_ij[2 * b] = i;
+    out_ij[2 * b + 1] = j;
+}
+
+} // namespace pdog

@@ -1,0 +1,425 @@
+// pawsome_dog.hip — host side of the C ABI declared in include/pawsome_dog.h.
+//
+// Mirrors the `Tracker` constructor (/root/reference/src/PawsomeTracker.jl:39-52):
+// σ and the two Gaussian factors of Kernel.DoG are built in Float64 on the host
+// exactly as the reference builds them, rounded to f32 once, and kept on the
+// device; the functor (:55-62) becomes kernel launches on a HIP stream.
+// There is NO CPU fallback: without a gfx950 device pdog_create fails.
+#include "../../include/pawsome_dog.h"
+#include "dog_kernels.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace pdog;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return fail(PDOG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));    \
+    } while (0)
+
+// ---- Float64 host arithmetic, as the reference does it ----
+double sigma_of(double tw) { return tw / (2.0 * std::sqrt(2.0 * std::log(2.0))); } // :30
+int kernel_len_of_sigma(double s) { return 4 * (int)std::ceil(s * std::sqrt(2.0)) + 1; } // Kernel.DoG
+void gaussian_1d(double s, int l, double *g)
+{ // KernelFactors.gaussian: exp(-x²/2σ²) / sum
+    const int w = l >> 1;
+    for (int x = -w; x <= w; ++x) g[x + w] = std::exp(-((double)x * (double)x) / (2.0 * s * s));
+    double sum = 0.0;
+    for (int i = 0; i < l; ++i) sum += g[i];
+    for (int i = 0; i < l; ++i) g[i] /= sum;
+}
+
+// ---- compiled kernel specialisations ----
+typedef void (*kernel_fn)(const LaunchGeo, const f2 *, const f2 *);
+struct Variant {
+    int id, P, XG, Q, CH, LT, NT;
+    kernel_fn fn, fn_resp; // fn_resp also writes the dense response (parity checks)
+    int tw() const { return P * XG; }
+    int ring(int L) const { return LT ? ring_rows(CH, LT, Q) : ring_rows(CH, L, Q); }
+    int pa(int L) const { return pitch_a(tw() + L - 1); }
+    size_t lds(int L) const
+    {
+        return (size_t)round_up(CH * pa(L) * 4, 16) + (size_t)ring(L) * pitch_r(tw()) * sizeof(f2);
+    }
+};
+#define PDOG_VARIANT(id, P, XG, Q, CH, LT, NT) \
+    Variant { id, P, XG, Q, CH, LT, NT, (kernel_fn)dog_window_kernel<P, XG, Q, CH, LT, NT, false>, \
+              (kernel_fn)dog_window_kernel<P, XG, Q, CH, LT, NT, true> }
+
+const Variant kVariants[] = {
+    // runtime-L (any target_width)
+    PDOG_VARIANT(0, 4, 8, 8, 32, 0, 256),
+    PDOG_VARIANT(1, 8, 8, 8, 32, 0, 256),
+    PDOG_VARIANT(2, 11, 8, 8, 32, 0, 256),
+    // l = 65 (target_width 25, the reference default)
+    PDOG_VARIANT(10, 11, 8, 16, 32, 65, 256),
+    PDOG_VARIANT(11, 11, 8, 8, 24, 65, 256),
+    PDOG_VARIANT(12, 8, 8, 16, 32, 65, 256),
+    PDOG_VARIANT(13, 8, 8, 8, 32, 65, 256),
+    PDOG_VARIANT(14, 11, 8, 8, 32, 65, 256),
+    // l = 29 (target_width 10, the reference test default)
+    PDOG_VARIANT(20, 8, 8, 4, 32, 29, 256),
+};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+constexpr size_t kMaxLds = 160 * 1024;
+
+const Variant *find_variant(int id)
+{
+    for (int i = 0; i < kNumVariants; ++i)
+        if (kVariants[i].id == id) return &kVariants[i];
+    return nullptr;
+}
+
+} // namespace
+
+struct pdog_tracker {
+    int device = 0;
+    int fh = 0, fw = 0, r1 = 0, r2 = 0, n1 = 0, n2 = 0, L = 0, fill = 0, darker = 0;
+    double tw = 0, sigma = 0;
+    const Variant *var = nullptr;
+    int nstrips = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    f2 *d_taps_row = nullptr, *d_taps_col = nullptr;
+    float *d_part_val = nullptr;
+    int *d_part_idx = nullptr;
+    int cap_windows = 0;
+    // host-path staging (pdog_detect_host / chain seed)
+    uint8_t *d_frame = nullptr;
+    int32_t *d_small = nullptr; // [0..1] guess, [2..3] result
+    float *d_resp = nullptr;
+};
+
+namespace {
+
+int choose_variant(pdog_tracker *t, int forced)
+{
+    const Variant *best = nullptr;
+    double best_cost = 0;
+    for (int i = 0; i < kNumVariants; ++i) {
+        const Variant &v = kVariants[i];
+        if (forced >= 0 && v.id != forced) continue;
+        if (v.LT != 0 && v.LT != t->L) continue;
+        if (v.lds(t->L) > kMaxLds) continue;
+        // crude cost: columns computed × per-column efficiency guess; compile-time L wins
+        const int strips = (t->n2 + v.tw() - 1) / v.tw();
+        double cost = (double)strips * v.tw() * (v.LT ? 1.0 : 1.6);
+        if (v.lds(t->L) > kMaxLds / 2) cost *= 1.3; // one workgroup per CU only
+        if (!best || cost < best_cost) { best = &v; best_cost = cost; }
+    }
+    if (!best) return fail(PDOG_E_ARG, "no kernel specialisation fits this target_width/window (LDS)");
+    t->var = best;
+    t->nstrips = (t->n2 + best->tw() - 1) / best->tw();
+    for (kernel_fn f : {best->fn, best->fn_resp}) {
+        hipError_t e = hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)best->lds(t->L));
+        if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    }
+    return PDOG_OK;
+}
+
+int ensure_capacity(pdog_tracker *t, int n)
+{
+    if (n <= t->cap_windows) return PDOG_OK;
+    // worst case strips over all variants so a later pdog_set_variant never reallocates
+    int max_strips = 1;
+    for (int i = 0; i < kNumVariants; ++i) max_strips = std::max(max_strips, (t->n2 + kVariants[i].tw() - 1) / kVariants[i].tw());
+    if (t->d_part_val) (void)hipFree(t->d_part_val);
+    if (t->d_part_idx) (void)hipFree(t->d_part_idx);
+    t->d_part_val = nullptr;
+    t->d_part_idx = nullptr;
+    t->cap_windows = 0;
+    HIP_TRY(hipMalloc(&t->d_part_val, sizeof(float) * (size_t)n * max_strips));
+    HIP_TRY(hipMalloc(&t->d_part_idx, sizeof(int) * (size_t)n * max_strips));
+    t->cap_windows = n;
+    return PDOG_OK;
+}
+
+int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
+                  const int32_t *d_frame_index, const int32_t *d_guesses, int n, int32_t *d_out_ij,
+                  float *d_out_resp)
+{
+    const Variant &v = *t->var;
+    LaunchGeo g;
+    g.frames = d_frames;
+    g.frame_stride = frame_stride;
+    g.row_stride = row_stride;
+    g.frame_index = d_frame_index;
+    g.guesses = d_guesses;
+    g.resp = d_out_resp;
+    g.part_val = t->d_part_val;
+    g.part_idx = t->d_part_idx;
+    g.fh = t->fh; g.fw = t->fw; g.r1 = t->r1; g.r2 = t->r2; g.n1 = t->n1; g.n2 = t->n2;
+    g.L = t->L; g.fill = t->fill; g.nstrips = t->nstrips; g.n = n;
+    g.RR = v.ring(t->L);
+    g.pitchA = v.pa(t->L);
+    g.nblocks = n * t->nstrips;
+    const int grid = round_up(g.nblocks, 8);
+    hipLaunchKernelGGL(d_out_resp ? v.fn_resp : v.fn, dim3(grid), dim3(v.NT), v.lds(t->L), t->stream, g,
+                       (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(dog_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, t->stream,
+                       t->d_part_val, t->d_part_idx, d_guesses, d_out_ij, n, t->nstrips,
+                       t->r1, t->r2, t->n1, t->fh, t->fw);
+    HIP_TRY(hipGetLastError());
+    return PDOG_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int pdog_abi_version(void) { return PDOG_ABI_VERSION; }
+const char *pdog_last_error(void) { return g_err.c_str(); }
+
+double pdog_sigma(double target_width) { return sigma_of(target_width); }
+int pdog_default_window(double target_width) { return 4 * (int)std::ceil(sigma_of(target_width)) + 1; } // :64-68
+int pdog_kernel_len(double target_width) { return kernel_len_of_sigma(sigma_of(target_width)); }
+
+int pdog_gaussian_taps(double target_width, int which, double *out, int cap)
+{
+    if (!out || (which != 0 && which != 1) || !(target_width > 0)) return fail(PDOG_E_ARG, "pdog_gaussian_taps: bad argument");
+    const double s = sigma_of(target_width);
+    const int l = kernel_len_of_sigma(s);
+    if (cap < l) return fail(PDOG_E_ARG, "pdog_gaussian_taps: buffer too small");
+    gaussian_1d(which ? s * std::sqrt(2.0) : s, l, out);
+    return PDOG_OK;
+}
+
+int pdog_mode_u8(const uint8_t *img, int h, int w, int64_t row_stride, int *out_mode)
+{
+    if (!img || !out_mode || h <= 0 || w <= 0 || row_stride < w) return fail(PDOG_E_ARG, "pdog_mode_u8: bad argument");
+    // StatsBase.mode over the h×w view, column-major scan (row index fastest): per-value
+    // running counts; the winner is the value whose count FIRST exceeds the running maximum.
+    // Equivalent single pass per column block: counts are order dependent only through ties,
+    // so keep the literal scan order.
+    int64_t cnt[256];
+    std::memset(cnt, 0, sizeof cnt);
+    int64_t mc = 0;
+    int mv = img[0];
+    for (int j = 0; j < w; ++j) {
+        const uint8_t *p = img + j;
+        for (int i = 0; i < h; ++i) {
+            const int v = p[(int64_t)i * row_stride];
+            const int64_t c = ++cnt[v];
+            if (c > mc) { mc = c; mv = v; }
+        }
+    }
+    *out_mode = mv;
+    return PDOG_OK;
+}
+
+int pdog_create(int device, int frame_h, int frame_w, double target_width, int win_h, int win_w,
+                int darker_target, int fill, pdog_tracker **out)
+{
+    if (!out) return fail(PDOG_E_ARG, "pdog_create: out is null");
+    *out = nullptr;
+    if (frame_h <= 0 || frame_w <= 0 || !(target_width > 0) || win_h < 0 || win_w < 0 || fill < 0 || fill > 255)
+        return fail(PDOG_E_ARG, "pdog_create: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(PDOG_E_NODEV, "pdog_create: no HIP device (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(PDOG_E_ARG, "pdog_create: device ordinal out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PDOG_E_NODEV, std::string("pdog_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    HIP_TRY(hipSetDevice(device));
+
+    pdog_tracker *t = new pdog_tracker();
+    t->device = device;
+    t->fh = frame_h; t->fw = frame_w;
+    t->tw = target_width;
+    t->sigma = sigma_of(target_width);             // :41
+    t->darker = darker_target ? 1 : 0;             // :42
+    t->L = kernel_len_of_sigma(t->sigma);          // :43
+    t->r1 = win_h / 2; t->r2 = win_w / 2;          // :44
+    t->n1 = 2 * t->r1 + 1; t->n2 = 2 * t->r2 + 1;  // :56
+    t->fill = fill;                                // :47
+    if ((long long)t->n1 * t->n2 > 0x3fffffffLL) { delete t; return fail(PDOG_E_ARG, "pdog_create: window too large"); }
+
+    int rc = choose_variant(t, -1);
+    if (rc) { delete t; return rc; }
+
+    // taps: Float64 on the host, one rounding to f32
+    std::vector<double> gp(t->L), gm(t->L);
+    gaussian_1d(t->sigma, t->L, gp.data());
+    gaussian_1d(t->sigma * std::sqrt(2.0), t->L, gm.data());
+    const double s = (t->darker ? -1.0 : 1.0) / 255.0; // direction (:42) and N0f8 scale
+    std::vector<f2> tr(t->L), tc(t->L);
+    for (int k = 0; k < t->L; ++k) {
+        tr[k] = f2{(float)gp[k], (float)gm[k]};
+        tc[k] = f2{(float)(s * gp[k]), (float)(-s * gm[k])};
+    }
+#define CREATE_TRY(expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            std::string m = std::string(#expr) + ": " + hipGetErrorString(e__);                   \
+            pdog_destroy(t);                                                                      \
+            return fail(PDOG_E_HIP, m);                                                           \
+        }                                                                                         \
+    } while (0)
+    CREATE_TRY(hipStreamCreateWithFlags(&t->own_stream, hipStreamNonBlocking));
+    t->stream = t->own_stream;
+    CREATE_TRY(hipMalloc(&t->d_taps_row, sizeof(f2) * t->L));
+    CREATE_TRY(hipMalloc(&t->d_taps_col, sizeof(f2) * t->L));
+    CREATE_TRY(hipMemcpy(t->d_taps_row, tr.data(), sizeof(f2) * t->L, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(t->d_taps_col, tc.data(), sizeof(f2) * t->L, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc(&t->d_small, sizeof(int32_t) * 4));
+#undef CREATE_TRY
+    rc = ensure_capacity(t, 1);
+    if (rc) { pdog_destroy(t); return rc; }
+    *out = t;
+    return PDOG_OK;
+}
+
+int pdog_destroy(pdog_tracker *t)
+{
+    if (!t) return PDOG_OK;
+    (void)hipSetDevice(t->device);
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    if (t->d_taps_row) (void)hipFree(t->d_taps_row);
+    if (t->d_taps_col) (void)hipFree(t->d_taps_col);
+    if (t->d_part_val) (void)hipFree(t->d_part_val);
+    if (t->d_part_idx) (void)hipFree(t->d_part_idx);
+    if (t->d_frame) (void)hipFree(t->d_frame);
+    if (t->d_small) (void)hipFree(t->d_small);
+    if (t->d_resp) (void)hipFree(t->d_resp);
+    if (t->own_stream) (void)hipStreamDestroy(t->own_stream);
+    delete t;
+    return PDOG_OK;
+}
+
+int pdog_get_info(const pdog_tracker *t, pdog_info *o)
+{
+    if (!t || !o) return fail(PDOG_E_ARG, "pdog_get_info: null");
+    o->frame_h = t->fh; o->frame_w = t->fw;
+    o->radius_h = t->r1; o->radius_w = t->r2;
+    o->win_h = t->n1; o->win_w = t->n2;
+    o->kernel_len = t->L;
+    o->fill = t->fill;
+    o->darker_target = t->darker;
+    o->n_strips = t->nstrips;
+    o->strip_w = t->var->tw();
+    o->variant = t->var->id;
+    o->sigma = t->sigma;
+    o->target_width = t->tw;
+    const int64_t th = t->n1 + t->L - 1, tw = t->n2 + t->L - 1;
+    o->algorithmic_bytes_per_window = th * tw + 8;
+    o->algorithmic_fma_per_window = 2LL * t->L * (th * t->n2 + (int64_t)t->n1 * t->n2);
+    return PDOG_OK;
+}
+
+int pdog_set_fill(pdog_tracker *t, int fill)
+{
+    if (!t || fill < 0 || fill > 255) return fail(PDOG_E_ARG, "pdog_set_fill: bad argument");
+    t->fill = fill;
+    return PDOG_OK;
+}
+
+int pdog_set_stream(pdog_tracker *t, void *hip_stream)
+{
+    if (!t) return fail(PDOG_E_ARG, "pdog_set_stream: null tracker");
+    t->stream = hip_stream ? (hipStream_t)hip_stream : t->own_stream;
+    return PDOG_OK;
+}
+
+int pdog_reserve(pdog_tracker *t, int max_windows)
+{
+    if (!t || max_windows <= 0) return fail(PDOG_E_ARG, "pdog_reserve: bad argument");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return ensure_capacity(t, max_windows);
+}
+
+int pdog_set_variant(pdog_tracker *t, int variant)
+{
+    if (!t) return fail(PDOG_E_ARG, "pdog_set_variant: null tracker");
+    if (variant >= 0 && !find_variant(variant)) return fail(PDOG_E_ARG, "pdog_set_variant: unknown variant id");
+    HIP_TRY(hipSetDevice(t->device));
+    return choose_variant(t, variant);
+}
+
+int pdog_sync(pdog_tracker *t)
+{
+    if (!t) return fail(PDOG_E_ARG, "pdog_sync: null tracker");
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return PDOG_OK;
+}
+
+int pdog_detect_batch(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
+                      int n_frames, const int32_t *d_frame_index, const int32_t *d_guesses, int n,
+                      int32_t *d_out_ij, float *d_out_resp)
+{
+    if (!t || !d_frames || !d_guesses || !d_out_ij) return fail(PDOG_E_ARG, "pdog_detect_batch: null pointer");
+    if (n < 0 || n_frames <= 0 || row_stride < t->fw || frame_stride < 0) return fail(PDOG_E_ARG, "pdog_detect_batch: bad size/stride");
+    if (!d_frame_index && n > n_frames) return fail(PDOG_E_ARG, "pdog_detect_batch: more windows than frames and no frame index");
+    if (n == 0) return PDOG_OK;
+    if ((long long)n * t->nstrips > 0x7ffffff0LL) return fail(PDOG_E_ARG, "pdog_detect_batch: batch too large");
+    HIP_TRY(hipSetDevice(t->device));
+    if (n > t->cap_windows) {
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        int rc = ensure_capacity(t, n);
+        if (rc) return rc;
+    }
+    return launch_detect(t, d_frames, frame_stride, row_stride, d_frame_index, d_guesses, n, d_out_ij, d_out_resp);
+}
+
+int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride, const int32_t guess[2],
+                     int32_t out_ij[2], float *h_resp)
+{
+    if (!t || !h_frame || !guess || !out_ij) return fail(PDOG_E_ARG, "pdog_detect_host: null pointer");
+    if (row_stride < t->fw) return fail(PDOG_E_ARG, "pdog_detect_host: row_stride < frame width");
+    // The reference's PaddedView extends radii + l past the frame (:45-46) and the filter
+    // reads radii + l÷2 around the guess: outside [-l÷2, sz + l÷2 + 1] it raises BoundsError.
+    const int hw = t->L >> 1;
+    if (guess[0] < -hw || guess[0] > t->fh + hw + 1 || guess[1] < -hw || guess[1] > t->fw + hw + 1)
+        return fail(PDOG_E_RANGE, "pdog_detect_host: guess outside the padded frame (reference: BoundsError)");
+    HIP_TRY(hipSetDevice(t->device));
+    if (!t->d_frame) HIP_TRY(hipMalloc(&t->d_frame, (size_t)t->fh * t->fw));
+    if (h_resp && !t->d_resp) HIP_TRY(hipMalloc(&t->d_resp, sizeof(float) * (size_t)t->n1 * t->n2));
+    HIP_TRY(hipMemcpy2DAsync(t->d_frame, t->fw, h_frame, row_stride, t->fw, t->fh, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->d_small, guess, sizeof(int32_t) * 2, hipMemcpyHostToDevice, t->stream));
+    int rc = launch_detect(t, t->d_frame, (int64_t)t->fh * t->fw, t->fw, nullptr, t->d_small, 1, t->d_small + 2,
+                           h_resp ? t->d_resp : nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out_ij, t->d_small + 2, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, t->stream));
+    if (h_resp) HIP_TRY(hipMemcpyAsync(h_resp, t->d_resp, sizeof(float) * (size_t)t->n1 * t->n2, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return PDOG_OK;
+}
+
+int pdog_detect_chain(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
+                      int n_frames, const int32_t start_guess[2], int32_t *d_out_ij)
+{
+    if (!t || !d_frames || !start_guess || !d_out_ij) return fail(PDOG_E_ARG, "pdog_detect_chain: null pointer");
+    if (n_frames <= 0 || row_stride < t->fw) return fail(PDOG_E_ARG, "pdog_detect_chain: bad size/stride");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipMemcpyAsync(t->d_small, start_guess, sizeof(int32_t) * 2, hipMemcpyHostToDevice, t->stream));
+    // frame k's guess is frame k-1's (clamped) answer, read straight from the output array:
+    // stream order is the dependency, no host round-trip per frame.
+    for (int k = 0; k < n_frames; ++k) {
+        const int32_t *guess = k ? d_out_ij + 2 * (k - 1) : t->d_small;
+        int rc = launch_detect(t, d_frames + (int64_t)k * frame_stride, frame_stride, row_stride, nullptr, guess, 1,
+                               d_out_ij + 2 * k, nullptr);
+        if (rc) return rc;
+    }
+    return PDOG_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,75 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol
+include/pawsome_dog.h declares, and its host-side helpers (Float64 scalar code, no kernels)
+agree with the oracle.  No compute calls without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pawsometracker_jl_amd as pt
+from pawsometracker_jl_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "pawsome_dog.h")).read()
+    declared = set(re.findall(r"\b(pdog_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.pdog_abi_version() == 1
+
+
+def test_scalar_helpers_match_oracle(oracle):
+    L = pt.lib()
+    for tw in (5, 10, 16, 25, 40, 77.5, 120):
+        assert L.pdog_sigma(tw) == oracle.sigma(tw)
+        assert L.pdog_default_window(tw) == oracle.default_window(tw)
+        l = L.pdog_kernel_len(tw)
+        assert l == oracle.kernel_len(oracle.sigma(tw))
+        for which, s in ((0, oracle.sigma(tw)), (1, oracle.sigma(tw) * 2 ** 0.5)):
+            out = np.empty(l)
+            assert L.pdog_gaussian_taps(tw, which, out.ctypes.data, l) == 0
+            assert np.array_equal(out, oracle.gaussian_1d(s, l))
+    assert L.pdog_gaussian_taps(25.0, 0, np.empty(3).ctypes.data, 3) == _lib.PDOG_E_ARG
+
+
+def test_mode_matches_oracle(oracle, golden):
+    for c in golden:
+        assert pt.mode(c["frame"]) == c["fill"]
+    assert pt.mode(np.array([[1, 2], [2, 1]], np.uint8)) == 2
+    view = np.zeros((6, 10), np.uint8)[:, 2:7]     # strided rows
+    view[:] = 9
+    assert pt.mode(view) == 9
+
+
+def test_host_bookkeeping():
+    assert pt.fix_window_size((30, 50)) == (50, 30)       # (w,h) -> (h,w), :70
+    assert pt.fix_window_size(45) == (45, 45)             # :72
+    assert pt.guess_window_size(25) == 45 and pt.guess_window_size(120) == 205
+    img = np.zeros((1080, 1920), np.uint8)
+    assert pt.get_guess(None, img) == (540, 960)          # :86-90
+    assert pt.get_guess(("ij", (5, 7)), img) == (5, 7)    # :74-77
+    assert pt.get_guess((100, 40), img, sar=2.0) == (40, 50)   # (x,y) -> round.((y, x/sar)), :79-84
+
+
+def test_shard_range_partitions():
+    for n, w in ((4096, 8), (8192, 8), (10, 3), (3, 8), (0, 2)):
+        spans = [pt.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pt.PdogError) as e:
+        pt.Tracker(np.full((32, 32), 128, np.uint8), 25, (45, 45), True)
+    assert e.value.code == _lib.PDOG_E_NODEV and "no CPU path" in str(e.value)

@@ -1,0 +1,231 @@
+"""Parity tests proper: the HIP path, called through the C ABI (ctypes), against the CPU oracle
+on the same inputs.  Bar: positions bit-exact; DoG response within 1e-5 relative Float32,
+where "relative" is max|gpu - ref| / max|ref| over the window (BASELINE.json north_star;
+pointwise relative error is meaningless where the response crosses zero).
+PARITY UNPINNED: the oracle is our restatement, see oracle/dog_oracle.c."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RESP_RTOL = 1e-5       # relative to max|ref| over the window
+RESP_ATOL = 1e-7       # for windows whose reference response is ~0 everywhere (flat: exact ties)
+
+
+@pytest.fixture(scope="module")
+def pt():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a device"
+    import pawsometracker_jl_amd as m
+    return m
+
+
+def _resp_err(got, ref):
+    scale = np.abs(ref).max()
+    err = np.abs(got.astype(np.float64) - ref).max()
+    return err, scale
+
+
+def _check_resp(got, ref, name):
+    err, scale = _resp_err(got, ref)
+    if scale < 1e-6:
+        assert err <= RESP_ATOL, (name, err, scale)
+    else:
+        assert err / scale <= RESP_RTOL, (name, err / scale)
+
+
+def test_golden_vectors_through_tracker(pt, golden):
+    for c in golden:
+        t = pt.Tracker(c["frame"], c["tw"], c["ws"], c["darker"])
+        assert t.img.fillvalue == c["fill"]
+        ij, resp = t(c["guess"], want_resp=True)
+        assert ij == c["ij"], (c["name"], ij, c["ij"])
+        _check_resp(resp, c["resp"], c["name"])
+        assert t(c["guess"]) == c["ij"]          # the no-response kernel instantiation
+        t.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 10, 11, 12, 13, 14])
+def test_every_l65_variant(pt, golden, variant):
+    for c in golden:
+        if c["l"] != 65:
+            continue
+        t = pt.Tracker(c["frame"], c["tw"], c["ws"], c["darker"])
+        t.set_variant(variant)
+        assert t.info().variant == variant
+        ij, resp = t(c["guess"], want_resp=True)
+        assert ij == c["ij"], (c["name"], variant, ij, c["ij"])
+        _check_resp(resp, c["resp"], c["name"])
+        assert t(c["guess"]) == c["ij"]
+        t.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 20])
+def test_other_kernel_lengths(pt, golden, variant):
+    for c in golden:
+        if c["l"] == 65 or (variant == 20 and c["l"] != 29):
+            continue
+        t = pt.Tracker(c["frame"], c["tw"], c["ws"], c["darker"])
+        try:
+            t.set_variant(variant)
+        except pt.PdogError:
+            t.close()
+            continue        # this variant's LDS footprint does not fit this kernel length
+        ij, resp = t(c["guess"], want_resp=True)
+        assert ij == c["ij"], (c["name"], variant, ij, c["ij"])
+        _check_resp(resp, c["resp"], c["name"])
+        t.close()
+
+
+def _batch(pt, frames, guesses, tw, ws, darker, fill, frame_index=None, want_resp=False, variant=None):
+    import torch
+    bt = pt.BatchTracker(frames.shape[1], frames.shape[2], tw, ws, darker, fill)
+    if variant is not None:
+        bt.set_variant(variant)
+    bt.use_torch_stream()
+    d_frames = torch.from_numpy(frames).cuda()
+    d_guess = torch.from_numpy(np.ascontiguousarray(guesses, np.int32)).cuda()
+    d_fi = torch.from_numpy(np.ascontiguousarray(frame_index, np.int32)).cuda() if frame_index is not None else None
+    out = bt.detect(d_frames, d_guess, d_fi, want_resp=want_resp)
+    torch.cuda.synchronize()
+    if want_resp:
+        res = out[0].cpu().numpy(), out[1].cpu().numpy()
+    else:
+        res = out.cpu().numpy()
+    bt.close()
+    return res
+
+
+def test_seeded_batch_vs_oracle(pt, oracle):
+    from oracle import synth
+    for tw, ws, darker, noise, seed in ((25, (45, 45), True, 3, 0), (25, (64, 96), False, 2, 1), (10, (21, 21), True, 3, 2)):
+        radii = (ws[0] // 2, ws[1] // 2)
+        frames, guesses, _ = synth.make_batch(24, 240, 320, tw, radii, darker, seed=seed, noise=noise)
+        fill = oracle.mode_u8(frames[0])
+        K = oracle.dog_kernel(oracle.sigma(tw), darker)
+        ref = oracle.detect_batch(frames, fill, K, radii, guesses)
+        got, resp = _batch(pt, frames, guesses, tw, ws, darker, fill, want_resp=True)
+        assert np.array_equal(got, ref), (tw, ws, np.flatnonzero((got != ref).any(1)))
+        for b in (0, 7, 23):
+            _, r = oracle.detect(frames[b], fill, K, radii, guesses[b], want_resp=True)
+            _check_resp(resp[b].T, r, f"batch{b}")
+
+
+def test_frame_index_many_windows_per_frame(pt, oracle):
+    from oracle import synth
+    tw, ws = 25, (45, 45)
+    frames, _, centres = synth.make_batch(3, 240, 320, tw, (22, 22), True, seed=5, noise=3)
+    rng = np.random.default_rng(7)
+    fi = rng.integers(0, 3, 40).astype(np.int32)
+    guesses = np.stack([rng.integers(1, 241, 40), rng.integers(1, 321, 40)], 1).astype(np.int32)
+    fill = oracle.mode_u8(frames[0])
+    K = oracle.dog_kernel(oracle.sigma(tw), True)
+    ref = np.array([oracle.detect(frames[fi[b]], fill, K, (22, 22), guesses[b]) for b in range(40)], np.int32)
+    got = _batch(pt, frames, guesses, tw, ws, True, fill, frame_index=fi)
+    assert np.array_equal(got, ref)
+
+
+def test_serial_chain_matches_oracle_chain(pt, oracle):
+    import torch
+    from oracle import synth
+    from oracle.dog_oracle import OracleTracker
+    tw, h, w = 10, 100, 100            # the reference test defaults (test/test-basic-test.jl:1-10)
+    rng = np.random.default_rng(3)
+    pos = np.cumsum(rng.integers(-4, 5, (60, 2)), 0) + 50
+    pos = np.clip(pos, 8, 92)
+    frames = np.stack([synth.disc_frame(h, w, (int(p[0]), int(p[1])), tw, True) for p in pos])
+    ot = OracleTracker(frames[0], tw, (21, 21), True, oracle)
+    ref = [ot((50, 50))]
+    for f in frames[1:]:
+        ot.data[...] = f
+        ref.append(ot(ref[-1]))
+    # device chain (pdog_detect_chain)
+    bt = pt.BatchTracker(h, w, tw, (21, 21), True, ot.fill)
+    out = bt.detect_chain(torch.from_numpy(frames).cuda(), (50, 50))
+    bt.sync()
+    assert [tuple(int(v) for v in r) for r in out.cpu().numpy()] == ref
+    bt.close()
+    # host mirror of the reference loop (Tracker + trckr.img.data, :166-167)
+    got = pt.track_frames(frames, target_width=tw, start_location=("ij", (50, 50)), window_size=21)
+    assert got == ref
+    assert ref == [(int(p[0]), int(p[1])) for p in pos]        # and it actually tracks the disc
+
+
+def test_auto_detect_bootstrap(pt, oracle):
+    # start_location === missing: window_size2 = sz .÷ 4 around the frame centre (:99-107)
+    from oracle import synth
+    h, w, tw = 240, 320, 25
+    f = synth.disc_frame(h, w, (130, 170), tw, True)
+    trckr, ij = pt.get_start_ij_and_tracker(None, f, tw, (45, 45), True)
+    K = oracle.dog_kernel(oracle.sigma(tw), True)
+    ref = oracle.detect(f, 128, K, ((h // 4) // 2, (w // 4) // 2), (h // 2, w // 2))
+    assert ij == ref == (130, 170)
+    assert trckr.radii == (22, 22)
+    trckr.close()
+
+
+def test_edge_cases(pt, oracle):
+    from pawsometracker_jl_amd import _lib
+    flat = np.full((64, 80), 77, np.uint8)
+    # 1x1 window (window_size 1 -> radii 0): the answer is the guess, clamped
+    t = pt.Tracker(flat, 25, (1, 1), True)
+    assert t((10, 20)) == (10, 20) and t((0, 81)) == (1, 80)
+    t.close()
+    # window larger than the frame, flat frame: top-left of the window, clamped -> (1, 1)
+    t = pt.Tracker(flat, 10, (201, 301), True)
+    assert t((32, 40)) == (1, 1)
+    t.close()
+    # guess further outside than the reference's pad allows -> PDOG_E_RANGE (reference: BoundsError)
+    t = pt.Tracker(flat, 25, (45, 45), True)
+    l = t.info().kernel_len
+    assert t((-(l // 2), 10)) == (1, 1)                  # last legal row
+    with pytest.raises(pt.PdogError) as e:
+        t((-(l // 2) - 1, 10))
+    assert e.value.code == _lib.PDOG_E_RANGE
+    t.close()
+    # empty batch is a no-op
+    import torch
+    bt = pt.BatchTracker(64, 80, 25, (45, 45), True, 77)
+    out = bt.detect(torch.zeros((1, 64, 80), dtype=torch.uint8, device="cuda"), torch.zeros((0, 2), dtype=torch.int32, device="cuda"))
+    assert out.shape == (0, 2)
+    bt.close()
+
+
+def test_full_size_properties_1080p(pt, oracle):
+    """BASELINE config 3 geometry (1080p, window 256 -> 257x257, tw=25) at a reduced batch:
+    size-independent properties + a few windows against the dense oracle."""
+    from oracle import synth
+    tw, ws, n = 25, (256, 256), 48
+    radii = (128, 128)
+    frames, guesses, centres = synth.make_batch(n, 1080, 1920, tw, radii, True, seed=11, noise=0)
+    fill = 128
+    got = _batch(pt, frames, guesses, tw, ws, True, fill)
+    # (i) noise-free disc fully inside frame and window -> exactly the disc centre
+    inside = ((centres[:, 0] > 13) & (centres[:, 0] < 1080 - 13) & (centres[:, 1] > 13) & (centres[:, 1] < 1920 - 13)
+              & (np.abs(centres - guesses) <= 128 - 13).all(1))
+    assert inside.sum() > n // 2
+    assert np.array_equal(got[inside], centres[inside])
+    # (iii) adding a constant to frame and fill changes nothing (sum K = 0)
+    got2 = _batch(pt, (frames.astype(np.int16) + 50).astype(np.uint8), guesses, tw, ws, True, fill + 50)
+    assert np.array_equal(got, got2)
+    # (iv) complement + bright target
+    got3 = _batch(pt, 255 - frames, guesses, tw, ws, False, 255 - fill)
+    assert np.array_equal(got, got3)
+    # (ii) flat frames -> window top-left, clamped
+    flat = np.full((2, 1080, 1920), 128, np.uint8)
+    g = np.array([[540, 960], [50, 1900]], np.int32)
+    assert np.array_equal(_batch(pt, flat, g, tw, ws, True, 128), np.array([[412, 832], [1, 1772]], np.int32))
+    # every compiled l=65 variant gives the same positions
+    for v in (10, 11, 12, 13, 14, 2):
+        assert np.array_equal(_batch(pt, frames, guesses, tw, ws, True, fill, variant=v), got), v
+    # noisy frames: a sample of windows against the dense Float64 oracle (279 M MAC each)
+    nf, ng, _ = synth.make_batch(4, 1080, 1920, tw, radii, True, seed=12, noise=3)
+    fill_n = oracle.mode_u8(nf[0])
+    K = oracle.dog_kernel(oracle.sigma(tw), True)
+    gotn, resp = _batch(pt, nf, ng, tw, ws, True, fill_n, want_resp=True)
+    for b in range(4):
+        ij, r = oracle.detect(nf[b], fill_n, K, radii, ng[b], want_resp=True)
+        assert tuple(int(v) for v in gotn[b]) == ij
+        _check_resp(resp[b].T, r, f"1080p{b}")
