@@ -89,7 +89,8 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width,
 int pdog_destroy(pdog_tracker *t);
 int pdog_get_info(const pdog_tracker *t, pdog_info *out);
 int pdog_set_fill(pdog_tracker *t, int fill);
-/* Launch on this hipStream_t (NULL = the tracker's own stream, the default). */
+/* Launch on this hipStream_t instead of the tracker's own stream (NULL = HIP's null stream,
+ * which is what torch.cuda.current_stream().cuda_stream reports for torch's default stream). */
 int pdog_set_stream(pdog_tracker *t, void *hip_stream);
 /* Pre-size the per-window workspace so pdog_detect_batch never allocates. */
 int pdog_reserve(pdog_tracker *t, int max_windows);

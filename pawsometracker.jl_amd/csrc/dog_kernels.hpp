@@ -9,7 +9,7 @@
 //
 // Algorithm (not the reference's: ImageFiltering runs the rank-2 DoG as ONE
 // dense l×l Float64 kernel; here it is two separable Gaussians in FP32):
-//   v      = pixel − fill                       (exact integer, kills the DC term: ΣK = 0)
+//   v      = pixel − dc                         (exact integer; dc = fill or the window mean: ΣK = 0)
 //   R±[a,x]= Σ_k g±[k] · v[a, x+k]              row pass (contiguous direction)
 //   D[y,x] = Σ_k (s·g+[k])·R+[y+k,x] + (−s·g−[k])·R−[y+k,x],  s = ±1/255   column pass
 // One workgroup owns one column strip of one window and streams input rows
@@ -211,6 +211,38 @@ __global__ __launch_bounds__(NT, 2) void dog_window_kernel(const LaunchGeo g, co
     const int NA = g.n1 + L - 1;           // input rows
     const int ws = min(TW, g.n2 - x0);     // valid output columns in this strip
 
+    // ---- per-window DC level ----
+    // ΣK = 0, so any constant may be subtracted from the pixels before filtering.  The
+    // reference's fill value (mode of frame 1) is the natural one: flat background becomes
+    // exactly 0 and flat windows tie exactly.  Where the window's content sits far from the
+    // fill (textured scenes), the two ~DC-sized Gaussian sums would cancel in FP32 with an
+    // error ∝ |DC|; there the rounded mean of a fixed 32×32 sample grid over the WINDOW's
+    // padded tile is used instead.  Every strip of a window samples the same pixels, so all
+    // its workgroups agree on the level (integer arithmetic, deterministic).
+    int dc;
+    {
+        const int tH = g.n1 + L - 1, tW = g.n2 + L - 1;
+        const int wj0 = g2 - g.r2 - 1 - hw; // 0-based frame col of the window tile's col 0
+        int sum = 0;
+        for (int k = tid; k < 1024; k += NT) {
+            const int gi = ti0 + (int)(((long long)(k >> 5) * tH) >> 5);
+            const int gj = wj0 + (int)(((long long)(k & 31) * tW) >> 5);
+            int v = g.fill;
+            if (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) v = frame[(long long)gi * g.row_stride + gj];
+            sum += v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+        int *ssum = reinterpret_cast<int *>(smem);
+        if (lane == 0) ssum[wave] = sum;
+        __syncthreads();
+        int tot = 0;
+        for (int w = 0; w < NW; ++w) tot += ssum[w];
+        __syncthreads();
+        dc = (tot + 512) >> 10;
+        if (abs(dc - g.fill) <= 8) dc = g.fill;
+    }
+
     float best = -__builtin_huge_valf();
     int best_idx = 0x7fffffff;
     int y_done = 0;
@@ -225,7 +257,7 @@ __global__ __launch_bounds__(NT, 2) void dog_window_kernel(const LaunchGeo g, co
                 const int gj = tj0 + c;
                 int v = g.fill;
                 if (rowok && gj >= 0 && gj < g.fw) v = src[gj];
-                A[r * PA + c] = (float)(v - g.fill);
+                A[r * PA + c] = (float)(v - dc);
             }
         }
         __syncthreads();

@@ -335,7 +335,7 @@ int pdog_set_fill(pdog_tracker *t, int fill)
 int pdog_set_stream(pdog_tracker *t, void *hip_stream)
 {
     if (!t) return fail(PDOG_E_ARG, "pdog_set_stream: null tracker");
-    t->stream = hip_stream ? (hipStream_t)hip_stream : t->own_stream;
+    t->stream = (hipStream_t)hip_stream;
     return PDOG_OK;
 }
 
@@ -366,10 +366,11 @@ int pdog_detect_batch(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_st
                       int n_frames, const int32_t *d_frame_index, const int32_t *d_guesses, int n,
                       int32_t *d_out_ij, float *d_out_resp)
 {
-    if (!t || !d_frames || !d_guesses || !d_out_ij) return fail(PDOG_E_ARG, "pdog_detect_batch: null pointer");
+    if (!t) return fail(PDOG_E_ARG, "pdog_detect_batch: null tracker");
+    if (n == 0) return PDOG_OK;
+    if (!d_frames || !d_guesses || !d_out_ij) return fail(PDOG_E_ARG, "pdog_detect_batch: null pointer");
     if (n < 0 || n_frames <= 0 || row_stride < t->fw || frame_stride < 0) return fail(PDOG_E_ARG, "pdog_detect_batch: bad size/stride");
     if (!d_frame_index && n > n_frames) return fail(PDOG_E_ARG, "pdog_detect_batch: more windows than frames and no frame index");
-    if (n == 0) return PDOG_OK;
     if ((long long)n * t->nstrips > 0x7ffffff0LL) return fail(PDOG_E_ARG, "pdog_detect_batch: batch too large");
     HIP_TRY(hipSetDevice(t->device));
     if (n > t->cap_windows) {
