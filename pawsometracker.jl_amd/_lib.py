@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpawsome_dog.so")
+# PAWSOME_DOG_LIB selects another build of the same library (tuning builds with ablation variants)
+LIB_PATH = os.environ.get("PAWSOME_DOG_LIB") or os.path.join(_HERE, "libpawsome_dog.so")
 
 PDOG_OK, PDOG_E_ARG, PDOG_E_HIP, PDOG_E_NODEV, PDOG_E_RANGE, PDOG_E_ALLOC = range(6)
 

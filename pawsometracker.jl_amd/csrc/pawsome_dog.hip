@@ -7,6 +7,7 @@
 // There is NO CPU fallback: without a gfx950 device pdog_create fails.
 #include "../../include/pawsome_dog.h"
 #include "dog_kernels.hpp"
+#include "dog_roll.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -50,17 +51,22 @@ typedef void (*kernel_fn)(const LaunchGeo, const f2 *, const f2 *);
 struct Variant {
     int id, P, XG, Q, CH, LT, NT;
     kernel_fn fn, fn_resp; // fn_resp also writes the dense response (parity checks)
+    bool roll;             // dog_roll.hpp (one wave per 64-column strip) instead of dog_kernels.hpp
     int tw() const { return P * XG; }
     int ring(int L) const { return LT ? ring_rows(CH, LT, Q) : ring_rows(CH, L, Q); }
     int pa(int L) const { return pitch_a(tw() + L - 1); }
     size_t lds(int L) const
     {
+        if (roll) return roll_lds_bytes();
         return (size_t)round_up(CH * pa(L) * 4, 16) + (size_t)ring(L) * pitch_r(tw()) * sizeof(f2);
     }
 };
 #define PDOG_VARIANT(id, P, XG, Q, CH, LT, NT) \
     Variant { id, P, XG, Q, CH, LT, NT, (kernel_fn)dog_window_kernel<P, XG, Q, CH, LT, NT, false>, \
-              (kernel_fn)dog_window_kernel<P, XG, Q, CH, LT, NT, true> }
+              (kernel_fn)dog_window_kernel<P, XG, Q, CH, LT, NT, true>, false }
+#define PDOG_ROLL_VARIANT(id, LT) \
+    Variant { id, ROLL_P, ROLL_TW / ROLL_P, ROLL_CH, ROLL_CH, LT, 64, (kernel_fn)dog_roll_kernel<LT, false>, \
+              (kernel_fn)dog_roll_kernel<LT, true>, true }
 
 const Variant kVariants[] = {
     // runtime-L (any target_width)
@@ -73,6 +79,14 @@ const Variant kVariants[] = {
     PDOG_VARIANT(12, 8, 8, 16, 32, 65, 256),
     PDOG_VARIANT(13, 8, 8, 8, 32, 65, 256),
     PDOG_VARIANT(14, 11, 8, 8, 32, 65, 256),
+    PDOG_ROLL_VARIANT(100, 65),
+#ifdef PDOG_ABLATIONS
+    Variant { 101, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 1>, (kernel_fn)dog_roll_kernel<65, true>, true },
+    Variant { 102, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 2>, (kernel_fn)dog_roll_kernel<65, true>, true },
+    Variant { 103, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 3>, (kernel_fn)dog_roll_kernel<65, true>, true },
+    Variant { 104, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 12>, (kernel_fn)dog_roll_kernel<65, true>, true },
+    Variant { 105, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 15>, (kernel_fn)dog_roll_kernel<65, true>, true },
+#endif
     // l = 29 (target_width 10, the reference test default)
     PDOG_VARIANT(20, 8, 8, 4, 32, 29, 256),
 };

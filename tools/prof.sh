@@ -1,0 +1,10 @@
+#!/bin/bash
+# usage: tools/prof.sh <tag> [bench args...]   — kernel trace + three PMC passes, condensed to gpurun_out/prof_<tag>.txt
+TAG=$1; shift
+P=/tmp/prof_$TAG; mkdir -p $P gpurun_out
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt -- python bench.py --steps 10 --warmup 2 --no-cpu "$@" > gpurun_out/prof_${TAG}_bench.json 2> $P/kt.err
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $P/pmc1 -- python bench.py --steps 3 --warmup 1 --no-cpu "$@" > /dev/null 2> $P/pmc1.err
+rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM --output-format csv -d $P/pmc2 -- python bench.py --steps 3 --warmup 1 --no-cpu "$@" > /dev/null 2> $P/pmc2.err
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_SCA --output-format csv -d $P/pmc3 -- python bench.py --steps 3 --warmup 1 --no-cpu "$@" > /dev/null 2> $P/pmc3.err
+python tools/prof_summary.py $P/kt $P/pmc1 $P/pmc2 $P/pmc3 | grep -A10 "kernel_stats\|kernel: void pdog::dog" | grep -v "at::native" | cut -c1-200 > gpurun_out/prof_${TAG}.txt
+cp $P/kt/*/*_kernel_stats.csv gpurun_out/kernel_stats_${TAG}.csv

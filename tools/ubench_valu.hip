@@ -22,6 +22,9 @@ __global__ void k(float *out, int iters, float seed)
                 if (MODE == 2) { a[i] = a[i] + t; }                                            // v_pk_add_f32
                 if (MODE == 3) { a[i].x = a[i].x + s; }                                        // v_add_f32
                 if (MODE == 4) { f2 b = {a[i].x, a[i].x}; a[i] = __builtin_elementwise_fma(b, t, a[i]); } // pk_fma bcast
+                if (MODE == 5) { asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i].x) : "s"(s), "v"(a[(i + 1) & 7].y)); } // SGPR operand
+                if (MODE == 6) { asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i].x) : "v"(s), "v"(a[(i + 1) & 7].y)); } // all VGPR
+                if (MODE == 7) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "s"(t)); } // pk with SGPR pair
             }
         }
     }
@@ -65,6 +68,9 @@ int main()
         run<4>("v_pk_fma bcast", w);
         run<2>("v_pk_add_f32", w);
         run<3>("v_add_f32", w);
+        run<5>("v_fmac v,s,v", w);
+        run<6>("v_fmac v,v,v", w);
+        run<7>("v_pk_fma v,s2", w);
     }
     return 0;
 }
