@@ -41,6 +41,8 @@ struct LaunchGeo {
     int fh, fw, r1, r2, n1, n2, L, fill, nstrips, n;
     int RR, pitchA;                      // only read by runtime-L variants
     int nblocks;                         // n * nstrips
+    int nslots;                          // partials per window: nstrips + thin columns
+    int thin_x0, nthin;                  // window columns [thin_x0, thin_x0+nthin) go to dog_thin_kernel
 };
 
 __host__ __device__ constexpr int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -354,8 +356,8 @@ __global__ __launch_bounds__(NT, 2) void dog_window_kernel(const LaunchGeo g, co
             const int oi = sidx[w];
             if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
         }
-        g.part_val[logical] = best;
-        g.part_idx[logical] = best_idx;
+        g.part_val[b * g.nslots + s] = best;
+        g.part_idx[b * g.nslots + s] = best_idx;
     }
 }
 

@@ -13,7 +13,8 @@
 //               window, symmetric taps: Σ_k g[k]·(a[x−k] + a[x+k]) — one v_add + one
 //               v_pk_fma_f32 (both Gaussians) per tap pair instead of two FMAs
 //       column pass  lane = column; the l partial sums a column has in flight live in
-//               REGISTERS (S = l−1+CH f32 accumulator slots, output y in slot y mod S), so each
+//               REGISTERS (S = l−1+CH f32 accumulator slots, output y in slot y mod S, two
+//               adjacent outputs per register pair / v_pk_fma_f32), so each
 //               R row is read from LDS exactly once (8 ds_read_b64 per sub-chunk per lane)
 //               instead of (Q+l−1)/Q times from a 64+ row LDS ring.  The slot ↔ tap
 //               mapping rotates by CH per sub-chunk; S/CH statically unrolled bodies are
@@ -40,18 +41,63 @@ constexpr int ROLL_PR = 65;  // R pitch (f2)
 __host__ __device__ constexpr int roll_slots(int L) { return L - 1 + ROLL_CH; }
 __host__ __device__ constexpr size_t roll_lds_bytes() { return (size_t)ROLL_CH * ROLL_PA * 4 + (size_t)ROLL_CH * ROLL_PR * 8; }
 
-// Row pass for one lane: P outputs, symmetric taps.  a = &A[r][P*gx] (72 inputs for l = 65).
-// out[o] = Σ_{k<H} T[k]·(a[o+k] + a[o+L-1-k]) + T[H]·a[o+H],  H = L/2, taps ascending.
+// The fixed 32×32 sample grid over the window's padded tile that decides the DC level (see
+// dog_kernels.hpp): thread `tid` of `nthreads` adds up its share; callers reduce and finish.
+__device__ __forceinline__ int dc_sample_sum(const LaunchGeo &g, const uint8_t *__restrict__ frame, int ti0, int wj0,
+                                             int L, int tid, int nthreads)
+{
+    const int tH = g.n1 + L - 1, tW = g.n2 + L - 1;
+    int sum = 0;
+    for (int k = tid; k < 1024; k += nthreads) {
+        const int gi = ti0 + (int)(((long long)(k >> 5) * tH) >> 5);
+        const int gj = wj0 + (int)(((long long)(k & 31) * tW) >> 5);
+        int v = g.fill;
+        if (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) v = frame[(long long)gi * g.row_stride + gj];
+        sum += v;
+    }
+    return sum;
+}
+__device__ __forceinline__ int dc_from_sum(int total, int fill)
+{
+    int dc = (total + 512) >> 10;
+    if (abs(dc - fill) <= 8) dc = fill;
+    return dc;
+}
+
+// Re-derive a tap pointer through an empty asm: the scalar loads that use it cannot be hoisted above
+// this point (hoisted, every block's taps are live at once and the SGPRs spill through v_writelane).
+// A fake use + redefinition of an accumulator pair: the FMAs that feed it cannot be sunk below this
+// point and later ones cannot be hoisted above it (keeps each tap block's FMAs next to its taps).
+__device__ __forceinline__ void pin_acc(f2 &a) { asm volatile("" : "+v"(a)); }
+
+__device__ __forceinline__ tap_ptr pin_taps(tap_ptr p)
+{
+    unsigned long long u = (unsigned long long)p;
+    asm volatile("" : "+s"(u));
+    return (tap_ptr)u;
+}
+
+// Row pass for one lane: P = 8 outputs, symmetric taps, everything in 4-cycle packed ops
+// (a lone wave issues one VALU instruction per ≈4.8 cycles whatever its width, so 2-cycle
+// scalar ops would leave the pipe half empty at 2 waves/SIMD):
+//   s2      = (a[o+k], a[o+1+k]) + (a[o+L-1-k], a[o+L-k])        v_pk_add_f32, o even
+//   acc[o]  += s2.x · (g+[k], g−[k]);  acc[o+1] += s2.y · (g+[k], g−[k])   v_pk_fma_f32 (op_sel broadcast)
+// VGPR pairs must be even-aligned, so the sliding windows hold register PAIRS (a[n], a[n+1]) for
+// every n (both parities), each read from LDS as one ds_read2_b32.
+// a = &A[r][P*gx]; inputs a[0 .. P+L-2].  Taps ascending k = 0..H-1, centre last: same order for
+// every output, so equal inputs give bit-equal outputs.
 template <int L>
 __device__ __forceinline__ void roll_row_pass(f2 (&acc)[ROLL_P], const float *a, tap_ptr taps)
 {
-    constexpr int P = ROLL_P, H = L / 2, U = 8;
+    constexpr int P = ROLL_P, H = L / 2, U = 4, NP = P / 2;
+    constexpr int W = 2 * (NP - 1) + U; // pairs per window: n = base + (2*op + u)
     static_assert(H % U == 0, "half length must be a multiple of the tap block");
-    float wlo[P + U - 1], whi[P + U - 1];
+    auto pair_at = [&](int n) { return f2{a[n], a[n + 1]}; };
+    f2 lo[W], hi[W];
 #pragma unroll
-    for (int j = 0; j < P + U - 1; ++j) {
-        wlo[j] = a[j];
-        whi[j] = a[L - 1 - (U - 1) + j]; // a[L-U+j]
+    for (int j = 0; j < W; ++j) {
+        lo[j] = pair_at(j);
+        hi[j] = pair_at(L - U + j); // base of the first hi window: (L-1) - (U-1)
     }
     f2 tn[U];
 #pragma unroll
@@ -61,88 +107,101 @@ __device__ __forceinline__ void roll_row_pass(f2 (&acc)[ROLL_P], const float *a,
         f2 t[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) t[j] = tn[j];
-        float nlo[U], nhi[U];
+        f2 nlo[U], nhi[U];
+        const tap_ptr tnext = pin_taps(taps + (k0 + U < H ? k0 + U : H));
         if (k0 + U < H) {
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                tn[j] = taps[k0 + U + j];
-                nlo[j] = a[k0 + U + (P - 1) + j];           // a[(k0+U) + 7 + j]
-                nhi[j] = a[L - U - (k0 + U) + j];           // lower end of the next hi window
+                tn[j] = tnext[j];
+                nlo[j] = pair_at(k0 + U + (W - U) + j); // new upper end of the next lo window
+                nhi[j] = pair_at(L - U - (k0 + U) + j); // new lower end of the next hi window
             }
         } else {
-            tn[0] = taps[H]; // centre tap
+            tn[0] = tnext[0]; // centre tap
+#pragma unroll
+            for (int j = 0; j < NP; ++j) nlo[j] = pair_at(H + 2 * j); // (a[o+H], a[o+1+H]), o = 2j
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
-            for (int o = 0; o < P; ++o) {
-                // lo = a[o + k0+u], hi = a[o + L-1-(k0+u)]
-                const float s = wlo[o + u] + whi[o + (U - 1) - u];
-                acc[o] = fma_bcast(s, t[u], acc[o]);
+            for (int op = 0; op < NP; ++op) {
+                const f2 s2 = lo[2 * op + u] + hi[2 * op + (U - 1) - u];
+                acc[2 * op] = fma_bcast(s2.x, t[u], acc[2 * op]);
+                acc[2 * op + 1] = fma_bcast(s2.y, t[u], acc[2 * op + 1]);
             }
         }
         if (k0 + U < H) {
 #pragma unroll
-            for (int j = 0; j < P - 1; ++j) wlo[j] = wlo[j + U];
+            for (int j = 0; j < W - U; ++j) lo[j] = lo[j + U];
 #pragma unroll
-            for (int j = 0; j < U; ++j) wlo[P - 1 + j] = nlo[j];
+            for (int j = 0; j < U; ++j) lo[W - U + j] = nlo[j];
 #pragma unroll
-            for (int j = P + U - 2; j >= U; --j) whi[j] = whi[j - U];
+            for (int j = W - 1; j >= U; --j) hi[j] = hi[j - U];
 #pragma unroll
-            for (int j = 0; j < U; ++j) whi[j] = nhi[j];
+            for (int j = 0; j < U; ++j) hi[j] = nhi[j];
+        } else {
+#pragma unroll
+            for (int op = 0; op < NP; ++op) {
+                acc[2 * op] = fma_bcast(nlo[op].x, tn[0], acc[2 * op]);
+                acc[2 * op + 1] = fma_bcast(nlo[op].y, tn[0], acc[2 * op + 1]);
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // centre tap: a[o + H]; after the last block wlo = a[H-U .. H-U+P+U-2], so a[o+H] = wlo[o+U] for o+U <= P+U-2
-    // and the last one (o = P-1) is whi[0+...]: whi = a[L-U-(H-U) + j] = a[H+1+j] → a[H+P-1] = whi[P-2]
 #pragma unroll
-    for (int o = 0; o < P; ++o) {
-        const float c = (o + U <= P + U - 2) ? wlo[o + U] : whi[P - 2];
-        acc[o] = fma_bcast(c, tn[0], acc[o]);
+        for (int o = 0; o < P; ++o) pin_acc(acc[o]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
+// Column-pass tap table for the rolling kernel (built on the host, pawsome_dog.hip): the f32
+// accumulators of two adjacent outputs (slots j, j+1, j even) share one register pair and one
+// v_pk_fma_f32 whose tap operand is the SGPR pair (T[t], T[t-1]).  Which t a row needs depends on
+// its parity p = a & 1 (t ≡ p mod 2), so there are two pairings; T[-1] = T[l] = 0.
+//   table[((qb*2 + p)*2 + c)*ROLL_QB + m] = (Tc[t], Tc[t-1]),  t = p + 2*(ROLL_QB*qb + m),
+//   c = 0: s·g+, c = 1: −s·g−
+constexpr int ROLL_QB = 2; // tap pairs per block (2 parities x 2 channels x QB pairs = 16 SGPRs, double-buffered)
+__host__ __device__ constexpr int roll_col_blocks(int L) { return ((L + 1) / 2 + ROLL_QB - 1) / ROLL_QB; }
+__host__ __device__ constexpr int roll_col_table_len(int L) { return roll_col_blocks(L) * 4 * ROLL_QB; } // in f2
+
 // Column pass body for sub-chunk phase SC (rows a ≡ CH*SC + i mod S).  rv[i] = (R+, R−)[row i][x].
+// Loop order (tap block, row, channel): every output receives its terms as t = 0: (+,−), 1: (+,−), …
+// whatever its alignment to blocks and sub-chunks, so equal inputs give bit-equal outputs.
 template <int L, int SC>
-__device__ __forceinline__ void roll_col_body(float (&acc)[roll_slots(L)], const f2 (&rv)[ROLL_CH], tap_ptr taps)
+__device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], const f2 (&rv)[ROLL_CH], tap_ptr table)
 {
-    constexpr int S = roll_slots(L), CH = ROLL_CH, U = 8;
-    constexpr int NB = (L + U - 1) / U;
-    f2 tn[U];
+    constexpr int S = roll_slots(L), CH = ROLL_CH, QB = ROLL_QB, NQB = roll_col_blocks(L);
+    static_assert(S % 2 == 0 && (CH * SC) % 2 == 0, "pairing needs even slot counts");
+    f2 tn[4 * QB];
 #pragma unroll
-    for (int j = 0; j < U; ++j) tn[j] = taps[j];
+    for (int j = 0; j < 4 * QB; ++j) tn[j] = table[j];
 #pragma unroll
-    for (int tb = 0; tb < NB; ++tb) {
-        f2 t[U];
+    for (int qb = 0; qb < NQB; ++qb) {
+        f2 t[4 * QB];
 #pragma unroll
-        for (int j = 0; j < U; ++j) t[j] = tn[j];
+        for (int j = 0; j < 4 * QB; ++j) t[j] = tn[j];
+        if (qb + 1 < NQB) {
+            const tap_ptr tnext = pin_taps(table + (qb + 1) * 4 * QB);
 #pragma unroll
-        for (int j = 0; j < U; ++j)
-            if ((tb + 1) * U + j < L) tn[j] = taps[(tb + 1) * U + j];
-        // One f32 accumulator per output: acc += (s·g+)·R+ then acc += (−s·g−)·R−.  Two
-        // v_fma_f32 cost the same VALU cycles as one v_pk_fma_f32 on gfx950 and halve the
-        // accumulator registers; the g+ terms of all slots are issued before the g− terms so
-        // that no FMA waits on the one before it.
+            for (int j = 0; j < 4 * QB; ++j) tn[j] = tnext[j];
+        }
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
+        for (int i = 0; i < CH; ++i) {
+            const int par = i & 1;
+            const int amod = CH * SC + i;
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
+            for (int c = 0; c < 2; ++c) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int tap = tb * U + u;
-                    if (tap < L) {
-                        const int amod = CH * SC + i;
-                        const int slot = ((amod - tap) % S + S) % S;
-                        const float r = ch ? rv[i].y : rv[i].x;
-                        const float w = ch ? t[u].y : t[u].x;
-                        if (tap == 0 && ch == 0)
-                            acc[slot] = r * w;             // first term of a new output: no stale accumulator
-                        else
-                            acc[slot] = __builtin_fmaf(r, w, acc[slot]);
+                for (int m = 0; m < QB; ++m) {
+                    const int tt = par + 2 * (QB * qb + m); // taps (tt, tt-1)
+                    if (tt - 1 <= L - 1) {
+                        const int slot = ((amod - tt) % S + S) % S; // even
+                        const float r = c ? rv[i].y : rv[i].x;
+                        acc2[slot / 2] = fma_bcast(r, t[(par * 2 + c) * QB + m], acc2[slot / 2]);
                     }
                 }
             }
         }
+#pragma unroll
+        for (int j = 0; j < S / 2; ++j) pin_acc(acc2[j]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -175,8 +234,9 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
     const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
     // strips are 64 wide; the last one is shifted left to stay inside the window (overlap
     // recomputes a few columns bit-identically), or is partial when the window is < 64 wide
-    const int x0 = (g.n2 >= TW) ? min(s * TW, g.n2 - TW) : 0;
-    const int ws = min(TW, g.n2);
+    const int ncols = g.nthin ? g.thin_x0 : g.n2; // columns covered by 64-wide strips
+    const int x0 = (ncols >= TW) ? min(s * TW, ncols - TW) : 0;
+    const int ws = min(TW, ncols);
     const int ti0 = g1 - g.r1 - 1 - hw;
     const int wj0 = g2 - g.r2 - 1 - hw; // frame col of the window tile's col 0
     const int tj0 = wj0 + x0;
@@ -185,20 +245,10 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
     // ---- per-window DC level (see dog_kernels.hpp): same samples in every strip ----
     int dc;
     {
-        const int tH = g.n1 + L - 1, tW = g.n2 + L - 1;
-        int sum = 0;
-#pragma unroll 4
-        for (int k = lane; k < 1024; k += 64) {
-            const int gi = ti0 + (int)(((long long)(k >> 5) * tH) >> 5);
-            const int gj = wj0 + (int)(((long long)(k & 31) * tW) >> 5);
-            int v = g.fill;
-            if (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) v = frame[(long long)gi * g.row_stride + gj];
-            sum += v;
-        }
+        int sum = dc_sample_sum(g, frame, ti0, wj0, L, lane, 64);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-        dc = (sum + 512) >> 10;
-        if (abs(dc - g.fill) <= 8) dc = g.fill;
+        dc = dc_from_sum(sum, g.fill);
     }
 
     // ---- staging geometry: lane → (row lane>>3, 16-byte segment lane&7) ----
@@ -227,9 +277,9 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         }
     };
 
-    float acc[S];
+    f2 acc2[S / 2];
 #pragma unroll
-    for (int j = 0; j < S; ++j) acc[j] = 0.f;
+    for (int j = 0; j < S / 2; ++j) acc2[j] = f2{0.f, 0.f};
     float best = -__builtin_huge_valf();
     int best_idx = 0x7fffffff;
 
@@ -278,7 +328,7 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         const int phase = sc % NBODY;
         auto emit = [&](auto SCc) {
             constexpr int SC = decltype(SCc)::value;
-            if (!(ABL & 1)) roll_col_body<L, SC>(acc, rv, tcol);
+            if (!(ABL & 1)) roll_col_body<L, SC>(acc2, rv, tcol);
             // outputs y = a − (l−1) for the 8 rows of this sub-chunk are complete
             const int ybase = sc * CH - (L - 1);
             if (ybase + CH > 0 && ybase < g.n1) {
@@ -291,7 +341,7 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
                     constexpr int dummy = 0; (void)dummy;
                     const int slot = ((CH * SC + i - (L - 1)) % S + S) % S;
                     const bool ok = colok && (ybase + i >= 0) && (ybase + i < g.n1);
-                    v[i] = acc[slot];
+                    v[i] = (slot & 1) ? acc2[slot / 2].y : acc2[slot / 2].x;
                     if (RESP && ok) g.resp[resp_base + lin0 + i] = v[i];
                     v[i] = ok ? v[i] : -__builtin_huge_valf();
                     m = fmaxf(m, v[i]);
@@ -301,6 +351,12 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
                     for (int i = 0; i < CH; ++i)
                         if (v[i] > best || (v[i] == best && lin0 + i < best_idx)) { best = v[i]; best_idx = lin0 + i; }
                 }
+            }
+            // the emitted slots start their next output from zero (they are reused S rows later)
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int slot = ((CH * SC + i - (L - 1)) % S + S) % S;
+                if (slot & 1) acc2[slot / 2].y = 0.f; else acc2[slot / 2].x = 0.f;
             }
         };
         switch (phase) {
@@ -324,8 +380,116 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
     }
     if (lane == 0) {
-        g.part_val[logical] = best;
-        g.part_idx[logical] = best_idx;
+        g.part_val[b * g.nslots + s] = best;
+        g.part_idx[b * g.nslots + s] = best_idx;
+    }
+}
+
+// ---- thin remainder ----
+// A window whose width is 64·k + r with small r (257 = 4·64 + 1) would need a whole extra strip for
+// r columns.  Instead those columns are done here, one 256-thread workgroup per (window, column):
+// thread = input row for the row pass (l contiguous pixels, symmetric taps), then thread = output row
+// for the column pass over the R column in LDS.  The arithmetic replays dog_roll_kernel's operation
+// order exactly (row: k ascending pairs then centre, both Gaussians per v_pk_fma_f32; column: per tap
+// t ascending, the g+ term then the g− term into one f32), so a pixel computed here is bit-identical
+// to what a strip would have produced and flat windows still tie exactly.
+template <int LT, bool RESP>
+__global__ __launch_bounds__(256) void dog_thin_kernel(const LaunchGeo g, const f2 *__restrict__ taps_row,
+                                                       const f2 *__restrict__ taps_col)
+{
+    constexpr int L = LT, hw = L / 2, H = L / 2, NT = 256, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f2 *Rc = reinterpret_cast<f2 *>(smem);            // NA entries
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / g.nthin;
+    const int rc = blockIdx.x - b * g.nthin;
+    const int x = g.thin_x0 + rc;                     // window column
+    const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
+    const int fidx = g.frame_index ? g.frame_index[b] : b;
+    const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
+    const int ti0 = g1 - g.r1 - 1 - hw;
+    const int wj0 = g2 - g.r2 - 1 - hw;
+    const int NA = g.n1 + L - 1;
+    const tap_ptr trow = as_taps(taps_row);
+    const tap_ptr tcol = as_taps(taps_col);
+
+    __shared__ int ssum[NW];
+    __shared__ float sval[NW];
+    __shared__ int sidx[NW];
+    int dc;
+    {
+        int sum = dc_sample_sum(g, frame, ti0, wj0, L, tid, NT);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        if (lane == 0) ssum[wave] = sum;
+        __syncthreads();
+        int tot = 0;
+        for (int w = 0; w < NW; ++w) tot += ssum[w];
+        dc = dc_from_sum(tot, g.fill);
+    }
+    const float fdc = (float)dc;
+
+    // ---- row pass: R[a] for input rows a = tid, tid + 256, … ----
+    const int gj0 = wj0 + x; // frame col of input k = 0
+    for (int a = tid; a < NA; a += NT) {
+        const int gi = ti0 + a;
+        float v[L];
+        const bool rowok = gi >= 0 && gi < g.fh;
+        if (rowok && gj0 >= 0 && gj0 + ((L + 3) & ~3) <= g.fw) {
+            const uint8_t *src = frame + (long long)gi * g.row_stride + gj0;
+#pragma unroll
+            for (int q = 0; q < (L + 3) / 4; ++q) {
+                uint32_t w;
+                __builtin_memcpy(&w, src + 4 * q, 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (4 * q + i < L) v[4 * q + i] = (float)((w >> (8 * i)) & 0xffu) - fdc;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                const int gj = gj0 + k;
+                int p = g.fill;
+                if (rowok && gj >= 0 && gj < g.fw) p = frame[(long long)gi * g.row_stride + gj];
+                v[k] = (float)p - fdc;
+            }
+        }
+        f2 acc = f2{0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < H; ++k) acc = fma_bcast(v[k] + v[L - 1 - k], trow[k], acc);
+        acc = fma_bcast(v[H], trow[H], acc);
+        Rc[a] = acc;
+    }
+    __syncthreads();
+    // ---- column pass + argmax: outputs y = tid, tid + 256, … ----
+    float best = -__builtin_huge_valf();
+    int best_idx = 0x7fffffff;
+    for (int y = tid; y < g.n1; y += NT) {
+        float acc = 0.f;
+#pragma unroll 13
+        for (int t = 0; t < L; ++t) {
+            const f2 r = Rc[y + t];
+            const f2 w = tcol[t];
+            acc = __builtin_fmaf(r.x, w.x, acc);
+            acc = __builtin_fmaf(r.y, w.y, acc);
+        }
+        const int lin = x * g.n1 + y;
+        if (RESP) g.resp[(long long)b * g.n1 * g.n2 + lin] = acc;
+        if (acc > best || (acc == best && lin < best_idx)) { best = acc; best_idx = lin; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_down(best, off, 64);
+        const int oi = __shfl_down(best_idx, off, 64);
+        if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
+    }
+    if (lane == 0) { sval[wave] = best; sidx[wave] = best_idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < NW; ++w)
+            if (sval[w] > best || (sval[w] == best && sidx[w] < best_idx)) { best = sval[w]; best_idx = sidx[w]; }
+        g.part_val[b * g.nslots + g.nstrips + rc] = best;
+        g.part_idx[b * g.nslots + g.nstrips + rc] = best_idx;
     }
 }
 

@@ -52,6 +52,7 @@ struct Variant {
     int id, P, XG, Q, CH, LT, NT;
     kernel_fn fn, fn_resp; // fn_resp also writes the dense response (parity checks)
     bool roll;             // dog_roll.hpp (one wave per 64-column strip) instead of dog_kernels.hpp
+    kernel_fn thin, thin_resp; // remainder-column kernel of the roll variants (may be null)
     int tw() const { return P * XG; }
     int ring(int L) const { return LT ? ring_rows(CH, LT, Q) : ring_rows(CH, L, Q); }
     int pa(int L) const { return pitch_a(tw() + L - 1); }
@@ -63,10 +64,11 @@ struct Variant {
 };
 #define PDOG_VARIANT(id, P, XG, Q, CH, LT, NT) \
     Variant { id, P, XG, Q, CH, LT, NT, (kernel_fn)dog_window_kernel<P, XG, Q, CH, LT, NT, false>, \
-              (kernel_fn)dog_window_kernel<P, XG, Q, CH, LT, NT, true>, false }
+              (kernel_fn)dog_window_kernel<P, XG, Q, CH, LT, NT, true>, false, nullptr, nullptr }
 #define PDOG_ROLL_VARIANT(id, LT) \
     Variant { id, ROLL_P, ROLL_TW / ROLL_P, ROLL_CH, ROLL_CH, LT, 64, (kernel_fn)dog_roll_kernel<LT, false>, \
-              (kernel_fn)dog_roll_kernel<LT, true>, true }
+              (kernel_fn)dog_roll_kernel<LT, true>, true, (kernel_fn)dog_thin_kernel<LT, false>, \
+              (kernel_fn)dog_thin_kernel<LT, true> }
 
 const Variant kVariants[] = {
     // runtime-L (any target_width)
@@ -81,17 +83,18 @@ const Variant kVariants[] = {
     PDOG_VARIANT(14, 11, 8, 8, 32, 65, 256),
     PDOG_ROLL_VARIANT(100, 65),
 #ifdef PDOG_ABLATIONS
-    Variant { 101, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 1>, (kernel_fn)dog_roll_kernel<65, true>, true },
-    Variant { 102, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 2>, (kernel_fn)dog_roll_kernel<65, true>, true },
-    Variant { 103, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 3>, (kernel_fn)dog_roll_kernel<65, true>, true },
-    Variant { 104, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 12>, (kernel_fn)dog_roll_kernel<65, true>, true },
-    Variant { 105, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 15>, (kernel_fn)dog_roll_kernel<65, true>, true },
+    Variant { 101, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 1>, (kernel_fn)dog_roll_kernel<65, true>, true, nullptr, nullptr },
+    Variant { 102, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 2>, (kernel_fn)dog_roll_kernel<65, true>, true, nullptr, nullptr },
+    Variant { 103, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 3>, (kernel_fn)dog_roll_kernel<65, true>, true, nullptr, nullptr },
+    Variant { 104, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 12>, (kernel_fn)dog_roll_kernel<65, true>, true, nullptr, nullptr },
+    Variant { 105, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 15>, (kernel_fn)dog_roll_kernel<65, true>, true, nullptr, nullptr },
 #endif
     // l = 29 (target_width 10, the reference test default)
     PDOG_VARIANT(20, 8, 8, 4, 32, 29, 256),
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr size_t kMaxLds = 160 * 1024;
+constexpr int kThinMax = 6; // remainder columns done by dog_thin_kernel instead of one more strip
 
 const Variant *find_variant(int id)
 {
@@ -108,8 +111,10 @@ struct pdog_tracker {
     double tw = 0, sigma = 0;
     const Variant *var = nullptr;
     int nstrips = 0;
+    int nthin = 0, thin_x0 = 0; // window columns handled by the thin-remainder kernel
     hipStream_t own_stream = nullptr, stream = nullptr;
     f2 *d_taps_row = nullptr, *d_taps_col = nullptr;
+    f2 *d_taps_roll = nullptr; // paired column-tap table of dog_roll.hpp
     float *d_part_val = nullptr;
     int *d_part_idx = nullptr;
     int cap_windows = 0;
@@ -134,11 +139,34 @@ int choose_variant(pdog_tracker *t, int forced)
         const int strips = (t->n2 + v.tw() - 1) / v.tw();
         double cost = (double)strips * v.tw() * (v.LT ? 1.0 : 1.6);
         if (v.lds(t->L) > kMaxLds / 2) cost *= 1.3; // one workgroup per CU only
+        if (v.roll) {
+            // barrier-free rolling kernel: ≈2× the ring kernels per column (measured, cfg3); thin
+            // remainder columns cost next to nothing
+            const int r = t->n2 % v.tw();
+            const int cols = (t->n2 > v.tw() && r > 0 && r <= kThinMax) ? t->n2 - r : strips * v.tw();
+            cost = 0.5 * cols;
+        }
         if (!best || cost < best_cost) { best = &v; best_cost = cost; }
     }
     if (!best) return fail(PDOG_E_ARG, "no kernel specialisation fits this target_width/window (LDS)");
     t->var = best;
     t->nstrips = (t->n2 + best->tw() - 1) / best->tw();
+    t->nthin = 0;
+    t->thin_x0 = 0;
+    if (best->roll && best->thin && t->n2 > best->tw()) {
+        // width = 64·k + r: r ≤ kThinMax columns are cheaper one by one than as an extra strip
+        const int r = t->n2 % best->tw();
+        const size_t thin_lds = sizeof(f2) * (size_t)(t->n1 + t->L - 1);
+        if (r > 0 && r <= kThinMax && thin_lds <= kMaxLds - 1024) {
+            for (kernel_fn f : {best->thin, best->thin_resp}) {
+                hipError_t e = hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)thin_lds);
+                if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("hipFuncSetAttribute(thin): ") + hipGetErrorString(e));
+            }
+            t->nthin = r;
+            t->thin_x0 = t->n2 - r;
+            t->nstrips = t->thin_x0 / best->tw();
+        }
+    }
     for (kernel_fn f : {best->fn, best->fn_resp}) {
         hipError_t e = hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)best->lds(t->L));
         if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
@@ -151,7 +179,8 @@ int ensure_capacity(pdog_tracker *t, int n)
     if (n <= t->cap_windows) return PDOG_OK;
     // worst case strips over all variants so a later pdog_set_variant never reallocates
     int max_strips = 1;
-    for (int i = 0; i < kNumVariants; ++i) max_strips = std::max(max_strips, (t->n2 + kVariants[i].tw() - 1) / kVariants[i].tw());
+    for (int i = 0; i < kNumVariants; ++i)
+        max_strips = std::max(max_strips, (t->n2 + kVariants[i].tw() - 1) / kVariants[i].tw() + kThinMax);
     if (t->d_part_val) (void)hipFree(t->d_part_val);
     if (t->d_part_idx) (void)hipFree(t->d_part_idx);
     t->d_part_val = nullptr;
@@ -182,12 +211,21 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     g.RR = v.ring(t->L);
     g.pitchA = v.pa(t->L);
     g.nblocks = n * t->nstrips;
+    g.nslots = t->nstrips + t->nthin;
+    g.thin_x0 = t->thin_x0;
+    g.nthin = t->nthin;
     const int grid = round_up(g.nblocks, 8);
     hipLaunchKernelGGL(d_out_resp ? v.fn_resp : v.fn, dim3(grid), dim3(v.NT), v.lds(t->L), t->stream, g,
-                       (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
+                       (const f2 *)t->d_taps_row, (const f2 *)(v.roll ? t->d_taps_roll : t->d_taps_col));
     HIP_TRY(hipGetLastError());
+    if (t->nthin) {
+        const size_t thin_lds = sizeof(f2) * (size_t)(t->n1 + t->L - 1);
+        hipLaunchKernelGGL(d_out_resp ? v.thin_resp : v.thin, dim3(n * t->nthin), dim3(256), thin_lds, t->stream, g,
+                           (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
+        HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(dog_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, t->stream,
-                       t->d_part_val, t->d_part_idx, d_guesses, d_out_ij, n, t->nstrips,
+                       t->d_part_val, t->d_part_idx, d_guesses, d_out_ij, n, g.nslots,
                        t->r1, t->r2, t->n1, t->fh, t->fw);
     HIP_TRY(hipGetLastError());
     return PDOG_OK;
@@ -294,6 +332,24 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
     CREATE_TRY(hipMalloc(&t->d_taps_col, sizeof(f2) * t->L));
     CREATE_TRY(hipMemcpy(t->d_taps_row, tr.data(), sizeof(f2) * t->L, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(t->d_taps_col, tc.data(), sizeof(f2) * t->L, hipMemcpyHostToDevice));
+    {
+        // roll_col_body's table: (Tc[t], Tc[t-1]) pairs per parity, T outside 0..l-1 is 0
+        const int nqb = roll_col_blocks(t->L);
+        std::vector<f2> tab((size_t)roll_col_table_len(t->L), f2{0.f, 0.f});
+        auto tapc = [&](int c, int k) -> float {
+            if (k < 0 || k >= t->L) return 0.f;
+            return c ? tc[k].y : tc[k].x;
+        };
+        for (int qb = 0; qb < nqb; ++qb)
+            for (int p = 0; p < 2; ++p)
+                for (int c = 0; c < 2; ++c)
+                    for (int m = 0; m < ROLL_QB; ++m) {
+                        const int tt = p + 2 * (ROLL_QB * qb + m);
+                        tab[((qb * 2 + p) * 2 + c) * ROLL_QB + m] = f2{tapc(c, tt), tapc(c, tt - 1)};
+                    }
+        CREATE_TRY(hipMalloc(&t->d_taps_roll, sizeof(f2) * tab.size()));
+        CREATE_TRY(hipMemcpy(t->d_taps_roll, tab.data(), sizeof(f2) * tab.size(), hipMemcpyHostToDevice));
+    }
     CREATE_TRY(hipMalloc(&t->d_small, sizeof(int32_t) * 4));
 #undef CREATE_TRY
     rc = ensure_capacity(t, 1);
@@ -309,6 +365,7 @@ int pdog_destroy(pdog_tracker *t)
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     if (t->d_taps_row) (void)hipFree(t->d_taps_row);
     if (t->d_taps_col) (void)hipFree(t->d_taps_col);
+    if (t->d_taps_roll) (void)hipFree(t->d_taps_roll);
     if (t->d_part_val) (void)hipFree(t->d_part_val);
     if (t->d_part_idx) (void)hipFree(t->d_part_idx);
     if (t->d_frame) (void)hipFree(t->d_frame);
