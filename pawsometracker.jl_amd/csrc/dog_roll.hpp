@@ -200,8 +200,15 @@ __device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], con
                 }
             }
         }
+        // pin exactly the pairs this block touched (pinning idle ones makes the allocator copy them)
 #pragma unroll
-        for (int j = 0; j < S / 2; ++j) pin_acc(acc2[j]);
+        for (int i = 0; i < CH; ++i) {
+#pragma unroll
+            for (int m = 0; m < QB; ++m) {
+                const int tt = (i & 1) + 2 * (QB * qb + m);
+                if (tt - 1 <= L - 1) pin_acc(acc2[(((CH * SC + i - tt) % S + S) % S) / 2]);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
 #pragma unroll
     for (int j = 0; j < S / 2; ++j) acc2[j] = f2{0.f, 0.f};
     float best = -__builtin_huge_valf();
-    int best_idx = 0x7fffffff;
+    int best_y = 0;
 
     const tap_ptr trow = as_taps(taps_row);
     const tap_ptr tcol = as_taps(taps_col);
@@ -329,27 +336,20 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         auto emit = [&](auto SCc) {
             constexpr int SC = decltype(SCc)::value;
             if (!(ABL & 1)) roll_col_body<L, SC>(acc2, rv, tcol);
-            // outputs y = a − (l−1) for the 8 rows of this sub-chunk are complete
+            // outputs y = a − (l−1) for the 8 rows of this sub-chunk are complete.  A lane owns ONE
+            // column and meets its rows in increasing y (= increasing column-major index), so a strict
+            // '>' keeps the first maximum of the lane (findmax, :59); ties between lanes and strips
+            // are settled by index in the reductions.  Column validity is applied once at the end.
             const int ybase = sc * CH - (L - 1);
             if (ybase + CH > 0 && ybase < g.n1) {
-                float v[CH];
-                float m = -__builtin_huge_valf();
-                const bool colok = lane < ws;
-                const int lin0 = (x0 + lane) * g.n1 + ybase;
+                const bool full = (ybase >= 0) && (ybase + CH <= g.n1); // wave-uniform
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
-                    constexpr int dummy = 0; (void)dummy;
                     const int slot = ((CH * SC + i - (L - 1)) % S + S) % S;
-                    const bool ok = colok && (ybase + i >= 0) && (ybase + i < g.n1);
-                    v[i] = (slot & 1) ? acc2[slot / 2].y : acc2[slot / 2].x;
-                    if (RESP && ok) g.resp[resp_base + lin0 + i] = v[i];
-                    v[i] = ok ? v[i] : -__builtin_huge_valf();
-                    m = fmaxf(m, v[i]);
-                }
-                if (m >= best && m > -__builtin_huge_valf()) {
-#pragma unroll
-                    for (int i = 0; i < CH; ++i)
-                        if (v[i] > best || (v[i] == best && lin0 + i < best_idx)) { best = v[i]; best_idx = lin0 + i; }
+                    const float v = (slot & 1) ? acc2[slot / 2].y : acc2[slot / 2].x;
+                    const bool rowok = full || ((ybase + i >= 0) && (ybase + i < g.n1));
+                    if (RESP && rowok && lane < ws) g.resp[resp_base + (long long)(x0 + lane) * g.n1 + ybase + i] = v;
+                    if (rowok && v > best) { best = v; best_y = ybase + i; }
                 }
             }
             // the emitted slots start their next output from zero (they are reused S rows later)
@@ -373,6 +373,8 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         __builtin_amdgcn_s_barrier(); // A / Rb are rewritten by the next sub-chunk
     }
 
+    int best_idx = (x0 + lane) * g.n1 + best_y;
+    if (lane >= ws) { best = -__builtin_huge_valf(); best_idx = 0x7fffffff; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float ov = __shfl_down(best, off, 64);
