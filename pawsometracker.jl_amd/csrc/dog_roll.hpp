@@ -32,7 +32,7 @@
 
 namespace pdog {
 
-constexpr int ROLL_CH = 8;   // rows per sub-chunk
+constexpr int ROLL_CH = 8;   // rows per sub-chunk (16 measured equal on cfg3: the kernel is VALU-bound, not latency-bound)
 constexpr int ROLL_P = 8;    // row-pass outputs per lane
 constexpr int ROLL_TW = 64;  // strip width = lanes
 constexpr int ROLL_PA = 129; // A pitch (f32): odd → conflict-free row-pass reads
@@ -223,7 +223,10 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
     constexpr int NBODY = S / CH;
     static_assert(S % CH == 0, "slot count must be a multiple of the sub-chunk");
     constexpr int TWin = TW + L - 1; // 128 input columns
-    static_assert(TWin == 128, "staging assumes 16 B per lane over 8 rows");
+    constexpr int SB = CH * TWin / 64; // staged bytes per lane per sub-chunk (16 or 32)
+    constexpr int SEGS = TWin / SB;    // lanes per row
+    static_assert(TWin == 128 && (SB == 16 || SB == 32), "staging assumes 16 or 32 B per lane");
+    constexpr int RPASS = CH / 8;      // row-pass rounds: 8 rows × 8 groups of P = 8 outputs per round
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *A = reinterpret_cast<float *>(smem);
@@ -258,22 +261,23 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         dc = dc_from_sum(sum, g.fill);
     }
 
-    // ---- staging geometry: lane → (row lane>>3, 16-byte segment lane&7) ----
-    const int srow = lane >> 3, sseg = lane & 7;
-    const int scol = tj0 + 16 * sseg;            // frame col of this lane's first byte
-    const bool cols_in = (scol >= 0) && (scol + 16 <= g.fw);
-    auto load16 = [&](int a_row, uint32_t (&w)[4]) {
+    // ---- staging geometry: lane → (row lane / SEGS, SB-byte segment lane % SEGS) ----
+    const int srow = lane / SEGS, sseg = lane % SEGS;
+    const int scol = tj0 + SB * sseg;            // frame col of this lane's first byte
+    const bool cols_in = (scol >= 0) && (scol + SB <= g.fw);
+    auto load16 = [&](int a_row, uint32_t (&w)[SB / 4]) {
         const int gi = ti0 + a_row;
         const bool rowok = (a_row < NA) && (gi >= 0) && (gi < g.fh);
         const uint32_t fill4 = (uint32_t)g.fill * 0x01010101u;
-        w[0] = w[1] = w[2] = w[3] = fill4;
+#pragma unroll
+        for (int q = 0; q < SB / 4; ++q) w[q] = fill4;
         if (rowok) {
             const uint8_t *src = frame + (long long)gi * g.row_stride + scol;
             if (cols_in) {
-                __builtin_memcpy(w, src, 16);
+                __builtin_memcpy(w, src, SB);
             } else {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
+                for (int i = 0; i < SB; ++i) {
                     const int gj = scol + i;
                     if (gj >= 0 && gj < g.fw) {
                         const uint32_t v = src[i];
@@ -293,7 +297,9 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
     const tap_ptr trow = as_taps(taps_row);
     const tap_ptr tcol = as_taps(taps_col);
 
-    uint32_t pre[4];
+    unsigned long long stamp_c0 = 0, stamp_r0 = 0;
+    if (ABL & 16) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
+    uint32_t pre[SB / 4];
     load16(srow, pre);
     const int nsub = (NA + CH - 1) / CH;
     const int rr = lane & 7, rgx = lane >> 3; // row-pass task: row rr, output group rgx
@@ -302,10 +308,10 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
     for (int sc = 0; sc < nsub; ++sc) {
         // ---- stage this sub-chunk from the prefetched registers, request the next ----
         if (!(ABL & 4)) {
-            float *dst = A + srow * ROLL_PA + 16 * sseg;
+            float *dst = A + srow * ROLL_PA + SB * sseg;
             const float fdc = (float)dc;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < SB; ++i) {
                 const uint32_t word = pre[i >> 2];
                 const float v = (float)((word >> (8 * (i & 3))) & 0xffu); // v_cvt_f32_ubyteN
                 dst[i] = v - fdc;
@@ -315,15 +321,18 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_barrier(); // single-wave workgroup: orders the LDS writes before the reads below
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        // ---- row pass: 8 rows × 8 groups of 8 outputs ----
+        // ---- row pass: rounds of 8 rows × 8 groups of 8 outputs ----
         if (!(ABL & 2)) {
-            f2 racc[P];
+#pragma unroll 1
+            for (int h = 0; h < RPASS; ++h) {
+                f2 racc[P];
 #pragma unroll
-            for (int o = 0; o < P; ++o) racc[o] = f2{0.f, 0.f};
-            roll_row_pass<L>(racc, A + rr * ROLL_PA + rgx * P, trow);
-            f2 *dst = Rb + rr * ROLL_PR + rgx * P;
+                for (int o = 0; o < P; ++o) racc[o] = f2{0.f, 0.f};
+                roll_row_pass<L>(racc, A + (rr + 8 * h) * ROLL_PA + rgx * P, trow);
+                f2 *dst = Rb + (rr + 8 * h) * ROLL_PR + rgx * P;
 #pragma unroll
-            for (int o = 0; o < P; ++o) dst[o] = racc[o];
+                for (int o = 0; o < P; ++o) dst[o] = racc[o];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_barrier();
@@ -359,6 +368,7 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
                 if (slot & 1) acc2[slot / 2].y = 0.f; else acc2[slot / 2].x = 0.f;
             }
         };
+        static_assert(NBODY <= 9, "extend the phase switch");
         switch (phase) {
         case 0: emit(std::integral_constant<int, 0>{}); break;
         case 1: emit(std::integral_constant<int, 1 % NBODY>{}); break;
@@ -373,6 +383,10 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         __builtin_amdgcn_s_barrier(); // A / Rb are rewritten by the next sub-chunk
     }
 
+    if (ABL & 16) { // diagnostic build only: shader cycles and 100 MHz ticks of the main loop, per wave
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && g.resp) { g.resp[2 * logical] = (float)(c1 - stamp_c0); g.resp[2 * logical + 1] = (float)(r1 - stamp_r0); }
+    }
     int best_idx = (x0 + lane) * g.n1 + best_y;
     if (lane >= ws) { best = -__builtin_huge_valf(); best_idx = 0x7fffffff; }
 #pragma unroll

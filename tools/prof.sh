@@ -8,3 +8,7 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_SCA --output-format csv -d $P/pmc3 -- python bench.py --steps 3 --warmup 1 --no-cpu "$@" > /dev/null 2> $P/pmc3.err
 python tools/prof_summary.py $P/kt $P/pmc1 $P/pmc2 $P/pmc3 | grep -A10 "kernel_stats\|kernel: void pdog::dog" | grep -v "at::native" | cut -c1-200 > gpurun_out/prof_${TAG}.txt
 cp $P/kt/*/*_kernel_stats.csv gpurun_out/kernel_stats_${TAG}.csv
+# HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (TCC slot limits, MI355X_MICROARCH.md §rocprofv3 PMC slots)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/pmc4 -- python bench.py --steps 3 --warmup 1 --no-cpu "$@" > /dev/null 2> $P/pmc4.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/pmc5 -- python bench.py --steps 3 --warmup 1 --no-cpu "$@" > /dev/null 2> $P/pmc5.err
+python tools/prof_summary.py $P/pmc4 $P/pmc5 | grep -A3 "kernel: void pdog::dog" | cut -c1-200 >> gpurun_out/prof_${TAG}.txt
