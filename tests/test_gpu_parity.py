@@ -229,3 +229,32 @@ def test_full_size_properties_1080p(pt, oracle):
         ij, r = oracle.detect(nf[b], fill_n, K, radii, ng[b], want_resp=True)
         assert tuple(int(v) for v in gotn[b]) == ij
         _check_resp(resp[b].T, r, f"1080p{b}")
+
+
+def test_random_geometries_vs_oracle(pt, oracle):
+    """Seeded random frame sizes / window sizes / guesses (borders included) for the three kernel
+    lengths the golden set exercises most: every strip layout of the roll kernel (partial strip,
+    overlapping last strip, thin remainder columns 1..6) and the ring kernels' chunk/strip edges."""
+    from oracle import synth
+    rng = np.random.default_rng(20260104)
+    cases = []
+    for wcols in (1, 7, 63, 64, 65, 66, 70, 71, 100, 127, 128, 129, 134, 135, 193):   # window widths 2r+1 are odd: use r
+        cases.append((25, int(rng.integers(3, 60)) | 1, wcols | 1))
+    for _ in range(6):
+        cases.append((int(rng.choice([10, 16, 25])), int(rng.integers(1, 90)) | 1, int(rng.integers(1, 150)) | 1))
+    for tw, wh, ww in cases:
+        h, w = int(rng.integers(40, 200)), int(rng.integers(60, 260))
+        centre = (int(rng.integers(1, h + 1)), int(rng.integers(1, w + 1)))
+        f = synth.disc_frame(h, w, centre, tw, True)
+        f = np.clip(f.astype(np.int16) + rng.integers(-4, 5, f.shape), 0, 255).astype(np.uint8)
+        guess = (int(np.clip(centre[0] + rng.integers(-wh // 3 - 1, wh // 3 + 2), -5, h + 6)),
+                 int(np.clip(centre[1] + rng.integers(-ww // 3 - 1, ww // 3 + 2), -5, w + 6)))
+        fill = oracle.mode_u8(f)
+        K = oracle.dog_kernel(oracle.sigma(tw), True)
+        ref_ij, ref = oracle.detect(f, fill, K, (wh // 2, ww // 2), guess, want_resp=True)
+        t = pt.Tracker(f, tw, (wh, ww), True)
+        ij, resp = t(guess, want_resp=True)
+        assert ij == ref_ij, (tw, wh, ww, h, w, guess, ij, ref_ij, t.info().variant)
+        _check_resp(resp, ref, f"rand tw={tw} win=({wh},{ww}) frame=({h},{w})")
+        assert t(guess) == ref_ij
+        t.close()
