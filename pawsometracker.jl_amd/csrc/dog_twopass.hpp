@@ -1,0 +1,244 @@
+// dog_twopass.hpp — DoG + argmax for LONG kernels (l ≳ 100, e.g. target_width 120 → l = 293).
+//
+// Same arithmetic contract as the other kernels (reference functor
+// /root/reference/src/PawsomeTracker.jl:55-62).  With l−1 ≈ 300 rows of halo neither the LDS ring
+// of dog_kernels.hpp (ring = (l−1+CH)·TW·8 B leaves room for ≤ 48 columns per CU) nor the register
+// accumulators of dog_roll.hpp (l slots per lane) fit, so the two separable passes become two
+// launches with the intermediate in HBM — affordable exactly because l is large: ≈590 FMA per
+// intermediate element against 16 B of traffic.
+//
+//   dog_dc_kernel     per-window DC level (see dog_kernels.hpp), once per batch
+//   dog_h1_kernel     ROW pass: 16 input rows → LDS once as f32 (pixel − dc); lane = (row, group of P
+//                     outputs), sliding register windows, symmetric taps (v_add_f32 + one
+//                     v_pk_fma_f32 for both Gaussians).  R is written TRANSPOSED, RT[x][a] (f2), so
+//                     that the column pass becomes another pass along contiguous memory.  (A lane-
+//                     per-column vertical pass over the strided u8 tile was tried first: 69 % of
+//                     its wave cycles were memory waits on byte loads.)
+//   dog_hpass_kernel  COLUMN pass + peak on RT: 16 RT rows (= 16 window columns x) → LDS once,
+//                     lane = (x, group of P outputs y), sliding window along a,
+//                     D = Σ (s·g₊)·R₊ + (−s·g₋)·R₋, running first maximum, workgroup reduction →
+//                     one partial per 16-column block.
+// Every output sees its taps in the same order (row pass: k ascending symmetric pairs then centre;
+// column pass: k ascending), so equal inputs give bit-equal outputs and flat windows tie exactly.
+#pragma once
+#include "dog_roll.hpp"
+
+namespace pdog {
+
+struct TwoPassGeo {
+    LaunchGeo g;
+    f2 *__restrict__ RT;    // [windows in this chunk][n2][NA]   (transposed row-pass result)
+    int *__restrict__ dc;   // [n]
+    int TWin;               // n2 + L − 1 tile columns
+    int NA;                 // n1 + L − 1 tile rows
+    int win0;               // first window of this chunk
+    int h1blocks_per_win;   // row-pass workgroups per window = ceil(NA / 16)
+    int hblocks_per_win;    // column-pass workgroups per window = ceil(n2 / 16)
+    int pitchA;             // LDS row pitch of the row pass, in floats
+    int pitchV;             // LDS row pitch of the column pass, in f2
+};
+
+__global__ __launch_bounds__(64) void dog_dc_kernel(const LaunchGeo g, int *__restrict__ dc)
+{
+    const int b = blockIdx.x, lane = threadIdx.x, hw = g.L >> 1;
+    const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
+    const int fidx = g.frame_index ? g.frame_index[b] : b;
+    const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
+    int sum = dc_sample_sum(g, frame, g1 - g.r1 - 1 - hw, g2 - g.r2 - 1 - hw, g.L, lane, 64);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) dc[b] = dc_from_sum(sum, g.fill);
+}
+
+// ---- row pass (u8 rows → RT) ----
+constexpr int HP_ROWS = 16; // rows per workgroup in both passes
+template <int P, int U>
+__global__ __launch_bounds__(256) void dog_h1_kernel(const TwoPassGeo tg, const f2 *__restrict__ taps_row)
+{
+    const LaunchGeo &g = tg.g;
+    constexpr int NT = 256, NW = NT / 64, XG = NT / HP_ROWS;
+    const int L = g.L, H = L >> 1, hw = L >> 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *A = reinterpret_cast<float *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b_local = blockIdx.x / tg.h1blocks_per_win;
+    const int rb = blockIdx.x - b_local * tg.h1blocks_per_win;
+    const int b = tg.win0 + b_local;
+    const int a0 = rb * HP_ROWS;
+    const int fidx = g.frame_index ? g.frame_index[b] : b;
+    const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
+    const int ti0 = g.guesses[2 * b] - g.r1 - 1 - hw;
+    const int wj0 = g.guesses[2 * b + 1] - g.r2 - 1 - hw;
+    const int dc = tg.dc[b];
+    // stage 16 tile rows as f32 (pixel − dc); outside the frame = fill − dc
+    for (int r = wave; r < HP_ROWS; r += NW) {
+        const int a = a0 + r, gi = ti0 + a;
+        const bool rowok = (a < tg.NA) && gi >= 0 && gi < g.fh;
+        const uint8_t *src = frame + (long long)gi * g.row_stride;
+        for (int c = lane; c < tg.TWin; c += 64) {
+            const int gj = wj0 + c;
+            int v = g.fill;
+            if (rowok && gj >= 0 && gj < g.fw) v = src[gj];
+            A[r * tg.pitchA + c] = (float)(v - dc);
+        }
+    }
+    __syncthreads();
+    const tap_ptr taps = as_taps(taps_row);
+    const int r = tid % HP_ROWS, gx = tid / HP_ROWS;
+    const int a = a0 + r;
+    for (int xb = gx * P; xb < g.n2; xb += XG * P) {
+        const float *in = A + r * tg.pitchA + xb; // inputs in[0 .. P+L-2]; clamp reads of masked outputs
+        const int imax = tg.TWin - 1 - xb;
+        auto ld = [&](int i) { return in[min(max(i, 0), imax)]; };
+        f2 acc[P];
+#pragma unroll
+        for (int o = 0; o < P; ++o) acc[o] = f2{0.f, 0.f};
+        float lo[P + U - 1], hi[P + U - 1];
+#pragma unroll
+        for (int j = 0; j < P + U - 1; ++j) {
+            lo[j] = ld(j);
+            hi[j] = ld(L - U + j);
+        }
+        int k0 = 0;
+        for (; k0 + U <= H; k0 += U) {
+            float nlo[U], nhi[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                nlo[j] = ld(k0 + U + (P - 1) + j);
+                nhi[j] = ld(L - U - (k0 + U) + j);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const f2 t = taps[k0 + u];
+#pragma unroll
+                for (int o = 0; o < P; ++o) acc[o] = fma_bcast(lo[o + u] + hi[o + (U - 1) - u], t, acc[o]);
+            }
+#pragma unroll
+            for (int j = 0; j < P - 1; ++j) lo[j] = lo[j + U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) lo[P - 1 + j] = nlo[j];
+#pragma unroll
+            for (int j = P + U - 2; j >= U; --j) hi[j] = hi[j - U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) hi[j] = nhi[j];
+        }
+        // remaining symmetric pairs (H − k0 < U) one tap at a time, then the centre tap
+        for (; k0 < H; ++k0) {
+            const f2 t = taps[k0];
+#pragma unroll
+            for (int o = 0; o < P; ++o) acc[o] = fma_bcast(ld(o + k0) + ld(o + L - 1 - k0), t, acc[o]);
+        }
+        {
+            const f2 t = taps[H];
+#pragma unroll
+            for (int o = 0; o < P; ++o) acc[o] = fma_bcast(ld(o + H), t, acc[o]);
+        }
+        if (a < tg.NA) {
+            f2 *dst = tg.RT + ((long long)b_local * g.n2 + xb) * tg.NA + a;
+#pragma unroll
+            for (int o = 0; o < P; ++o)
+                if (xb + o < g.n2) dst[(long long)o * tg.NA] = acc[o];
+        }
+    }
+}
+
+// ---- column pass + peak (on RT) ----
+template <int P, int U, bool RESP>
+__global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, const f2 *__restrict__ taps_col)
+{
+    const LaunchGeo &g = tg.g;
+    constexpr int NT = 256, NW = NT / 64, XG = NT / HP_ROWS;
+    const int L = g.L;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f2 *Vs = reinterpret_cast<f2 *>(smem);
+    __shared__ float sval[NW];
+    __shared__ int sidx[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b_local = blockIdx.x / tg.hblocks_per_win;
+    const int rb = blockIdx.x - b_local * tg.hblocks_per_win;
+    const int b = tg.win0 + b_local;
+    const int r0 = rb * HP_ROWS;                 // first window column x of this block
+    const int nrows = min(HP_ROWS, g.n2 - r0);
+    // stage: nrows × NA f2, coalesced
+    {
+        const f2 *src = tg.RT + ((long long)b_local * g.n2 + r0) * tg.NA;
+        for (int r = wave; r < HP_ROWS; r += NW) {
+            f2 *dst = Vs + r * tg.pitchV;
+            if (r < nrows) {
+                for (int c = lane; c < tg.NA; c += 64) dst[c] = src[(long long)r * tg.NA + c];
+            } else {
+                for (int c = lane; c < tg.NA; c += 64) dst[c] = f2{0.f, 0.f};
+            }
+        }
+    }
+    __syncthreads();
+    const tap_ptr taps = as_taps(taps_col);
+    const int r = tid % HP_ROWS, gx = tid / HP_ROWS;
+    float best = -__builtin_huge_valf();
+    int best_idx = 0x7fffffff;
+    // a workgroup covers XG·P columns per round; wide windows take several rounds
+    for (int xb = gx * P; xb < g.n1; xb += XG * P) { // xb: first output row y of this lane's group
+        const f2 *a = Vs + r * tg.pitchV + xb;
+        f2 acc[P];
+#pragma unroll
+        for (int o = 0; o < P; ++o) acc[o] = f2{0.f, 0.f};
+        // the window may run past the staged row for masked outputs (x ≥ n2): clamp the reads
+        const int amax = tg.NA - 1 - xb;
+        auto ld = [&](int i) { return a[min(i, amax)]; };
+        f2 win[P + U - 1];
+#pragma unroll
+        for (int j = 0; j < P + U - 1; ++j) win[j] = ld(j);
+        int k0 = 0;
+        for (; k0 + U <= L; k0 += U) {
+            f2 nw[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) nw[j] = ld(k0 + U + (P - 1) + j);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const f2 t = taps[k0 + u];
+#pragma unroll
+                for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[o + u], t, acc[o]);
+            }
+#pragma unroll
+            for (int j = 0; j < P - 1; ++j) win[j] = win[j + U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) win[P - 1 + j] = nw[j];
+        }
+        for (; k0 < L; ++k0) { // l mod U leftover taps, one at a time (window = win[0..P-1] shifted by one)
+            const f2 t = taps[k0];
+#pragma unroll
+            for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[o], t, acc[o]);
+#pragma unroll
+            for (int j = 0; j < P + U - 2; ++j) win[j] = win[j + 1];
+        }
+        if (r < nrows) {
+            const int x = r0 + r;
+#pragma unroll
+            for (int o = 0; o < P; ++o) {
+                const int y = xb + o;
+                if (y < g.n1) {
+                    const float v = acc[o].x + acc[o].y;
+                    const int lin = x * g.n1 + y;
+                    if (RESP) g.resp[(long long)b * g.n1 * g.n2 + lin] = v;
+                    if (v > best) { best = v; best_idx = lin; } // y ascending ⇒ lin ascending: strict > keeps the first
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_down(best, off, 64);
+        const int oi = __shfl_down(best_idx, off, 64);
+        if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
+    }
+    if (lane == 0) { sval[wave] = best; sidx[wave] = best_idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < NW; ++w)
+            if (sval[w] > best || (sval[w] == best && sidx[w] < best_idx)) { best = sval[w]; best_idx = sidx[w]; }
+        g.part_val[b * g.nslots + rb] = best;
+        g.part_idx[b * g.nslots + rb] = best_idx;
+    }
+}
+
+} // namespace pdog

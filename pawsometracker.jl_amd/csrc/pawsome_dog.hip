@@ -8,6 +8,7 @@
 #include "../../include/pawsome_dog.h"
 #include "dog_kernels.hpp"
 #include "dog_roll.hpp"
+#include "dog_twopass.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -53,11 +54,13 @@ struct Variant {
     kernel_fn fn, fn_resp; // fn_resp also writes the dense response (parity checks)
     bool roll;             // dog_roll.hpp (one wave per 64-column strip) instead of dog_kernels.hpp
     kernel_fn thin, thin_resp; // remainder-column kernel of the roll variants (may be null)
+    int twopass = 0;           // dog_twopass.hpp: vertical pass → HBM → horizontal pass (Q = this value)
     int tw() const { return P * XG; }
     int ring(int L) const { return LT ? ring_rows(CH, LT, Q) : ring_rows(CH, L, Q); }
     int pa(int L) const { return pitch_a(tw() + L - 1); }
     size_t lds(int L) const
     {
+        if (twopass) return 0; // sized per window width at launch
         if (roll) return roll_lds_bytes();
         return (size_t)round_up(CH * pa(L) * 4, 16) + (size_t)ring(L) * pitch_r(tw()) * sizeof(f2);
     }
@@ -82,6 +85,8 @@ const Variant kVariants[] = {
     PDOG_VARIANT(13, 8, 8, 8, 32, 65, 256),
     PDOG_VARIANT(14, 11, 8, 8, 32, 65, 256),
     PDOG_ROLL_VARIANT(100, 65),
+    // any l: two launches with the intermediate in HBM (long kernels, target_width ≳ 40)
+    Variant { 200, 13, 16, 16, 16, 0, 256, nullptr, nullptr, false, nullptr, nullptr, 16 },
 #ifdef PDOG_ABLATIONS
     Variant { 101, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 1>, (kernel_fn)dog_roll_kernel<65, true>, true, nullptr, nullptr },
     Variant { 102, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 2>, (kernel_fn)dog_roll_kernel<65, true>, true, nullptr, nullptr },
@@ -113,6 +118,11 @@ struct pdog_tracker {
     const Variant *var = nullptr;
     int nstrips = 0;
     int nthin = 0, thin_x0 = 0; // window columns handled by the thin-remainder kernel
+    // two-pass path scratch
+    f2 *d_V = nullptr;
+    size_t v_bytes = 0;
+    int *d_dc = nullptr;
+    int dc_cap = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     f2 *d_taps_row = nullptr, *d_taps_col = nullptr;
     f2 *d_taps_roll = nullptr; // paired column-tap table of dog_roll.hpp
@@ -136,6 +146,14 @@ int choose_variant(pdog_tracker *t, int forced)
         if (forced >= 0 && v.id != forced) continue;
         if (v.LT != 0 && v.LT != t->L) continue;
         if (v.lds(t->L) > kMaxLds) continue;
+        if (forced < 0 && t->L >= 80 && !v.twopass) continue; // long kernels: two-pass path (measured 1.7× the ring kernel at l = 293)
+        if (v.twopass) {
+            const size_t hl = (size_t)HP_ROWS * ((t->n1 + t->L - 1) | 1) * sizeof(f2);
+            if (hl > kMaxLds - 1024) continue;
+            if (forced < 0 && t->L < 80) continue; // the ring/roll kernels win for short kernels
+            if (!best || forced >= 0) { best = &v; best_cost = 0.0; }
+            continue;
+        }
         // crude cost: columns computed × per-column efficiency guess; compile-time L wins
         const int strips = (t->n2 + v.tw() - 1) / v.tw();
         double cost = (double)strips * v.tw() * (v.LT ? 1.0 : 1.6);
@@ -154,6 +172,18 @@ int choose_variant(pdog_tracker *t, int forced)
     t->nstrips = (t->n2 + best->tw() - 1) / best->tw();
     t->nthin = 0;
     t->thin_x0 = 0;
+    if (best->twopass) {
+        t->nstrips = (t->n2 + HP_ROWS - 1) / HP_ROWS; // partial slots = 16-column blocks
+        const int hl = (int)((size_t)HP_ROWS * ((t->n1 + t->L - 1) | 1) * sizeof(f2));
+        const int h1l = (int)((size_t)HP_ROWS * ((t->n2 + t->L - 1) | 1) * sizeof(float));
+        for (const void *f : {(const void *)dog_hpass_kernel<13, 16, false>, (const void *)dog_hpass_kernel<13, 16, true>}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, hl);
+            if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("hipFuncSetAttribute(hpass): ") + hipGetErrorString(e));
+        }
+        hipError_t e = hipFuncSetAttribute((const void *)dog_h1_kernel<13, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, h1l);
+        if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("hipFuncSetAttribute(h1): ") + hipGetErrorString(e));
+        return PDOG_OK;
+    }
     if (best->roll && best->thin && t->n2 > best->tw()) {
         // width = 64·k + r: r ≤ kThinMax columns are cheaper one by one than as an extra strip
         const int r = t->n2 % best->tw();
@@ -182,6 +212,7 @@ int ensure_capacity(pdog_tracker *t, int n)
     int max_strips = 1;
     for (int i = 0; i < kNumVariants; ++i)
         max_strips = std::max(max_strips, (t->n2 + kVariants[i].tw() - 1) / kVariants[i].tw() + kThinMax);
+    max_strips = std::max(max_strips, (t->n2 + HP_ROWS - 1) / HP_ROWS);
     if (t->d_part_val) (void)hipFree(t->d_part_val);
     if (t->d_part_idx) (void)hipFree(t->d_part_idx);
     t->d_part_val = nullptr;
@@ -215,6 +246,58 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     g.nslots = t->nstrips + t->nthin;
     g.thin_x0 = t->thin_x0;
     g.nthin = t->nthin;
+    if (v.twopass) {
+        g.nslots = t->nstrips;
+        g.nthin = 0;
+        TwoPassGeo tg;
+        tg.g = g;
+        tg.TWin = t->n2 + t->L - 1;
+        tg.NA = t->n1 + t->L - 1;
+        tg.h1blocks_per_win = (tg.NA + HP_ROWS - 1) / HP_ROWS;
+        tg.hblocks_per_win = t->nstrips;
+        tg.pitchA = tg.TWin | 1;
+        tg.pitchV = tg.NA | 1;
+        const size_t per_win = (size_t)t->n2 * tg.NA * sizeof(f2);
+        const size_t cap = (size_t)6 << 30;
+        const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, cap / per_win));
+        if (t->v_bytes < per_win * chunk || t->dc_cap < n) {
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            if (t->v_bytes < per_win * chunk) {
+                if (t->d_V) (void)hipFree(t->d_V);
+                t->d_V = nullptr; t->v_bytes = 0;
+                HIP_TRY(hipMalloc(&t->d_V, per_win * chunk));
+                t->v_bytes = per_win * chunk;
+            }
+            if (t->dc_cap < n) {
+                if (t->d_dc) (void)hipFree(t->d_dc);
+                t->d_dc = nullptr; t->dc_cap = 0;
+                HIP_TRY(hipMalloc(&t->d_dc, sizeof(int) * (size_t)n));
+                t->dc_cap = n;
+            }
+        }
+        tg.RT = t->d_V;
+        tg.dc = t->d_dc;
+        hipLaunchKernelGGL(dog_dc_kernel, dim3(n), dim3(64), 0, t->stream, g, t->d_dc);
+        HIP_TRY(hipGetLastError());
+        const size_t l1 = (size_t)HP_ROWS * tg.pitchA * sizeof(float);
+        const size_t l2 = (size_t)HP_ROWS * tg.pitchV * sizeof(f2);
+        for (int w0 = 0; w0 < n; w0 += chunk) {
+            const int nw = std::min(chunk, n - w0);
+            tg.win0 = w0;
+            hipLaunchKernelGGL((dog_h1_kernel<13, 8>), dim3(nw * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
+            HIP_TRY(hipGetLastError());
+            if (d_out_resp)
+                hipLaunchKernelGGL((dog_hpass_kernel<13, 16, true>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
+            else
+                hipLaunchKernelGGL((dog_hpass_kernel<13, 16, false>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(dog_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, t->stream,
+                           t->d_part_val, t->d_part_idx, d_guesses, d_out_ij, n, g.nslots,
+                           t->r1, t->r2, t->n1, t->fh, t->fw);
+        HIP_TRY(hipGetLastError());
+        return PDOG_OK;
+    }
     const int grid = round_up(g.nblocks, 8);
     hipLaunchKernelGGL(d_out_resp ? v.fn_resp : v.fn, dim3(grid), dim3(v.NT), v.lds(t->L), t->stream, g,
                        (const f2 *)t->d_taps_row, (const f2 *)(v.roll ? t->d_taps_roll : t->d_taps_col));
@@ -372,6 +455,8 @@ int pdog_destroy(pdog_tracker *t)
     if (t->d_frame) (void)hipFree(t->d_frame);
     if (t->d_small) (void)hipFree(t->d_small);
     if (t->d_resp) (void)hipFree(t->d_resp);
+    if (t->d_V) (void)hipFree(t->d_V);
+    if (t->d_dc) (void)hipFree(t->d_dc);
     if (t->own_stream) (void)hipStreamDestroy(t->own_stream);
     delete t;
     return PDOG_OK;

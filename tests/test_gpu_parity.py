@@ -47,7 +47,7 @@ def test_golden_vectors_through_tracker(pt, golden):
         t.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 10, 11, 12, 13, 14, 100])
+@pytest.mark.parametrize("variant", [0, 1, 2, 10, 11, 12, 13, 14, 100, 200])
 def test_every_l65_variant(pt, golden, variant):
     for c in golden:
         if c["l"] != 65:
@@ -62,7 +62,7 @@ def test_every_l65_variant(pt, golden, variant):
         t.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 20])
+@pytest.mark.parametrize("variant", [0, 1, 2, 20, 200])
 def test_other_kernel_lengths(pt, golden, variant):
     for c in golden:
         if c["l"] == 65 or (variant == 20 and c["l"] != 29):
@@ -218,7 +218,7 @@ def test_full_size_properties_1080p(pt, oracle):
     g = np.array([[540, 960], [50, 1900]], np.int32)
     assert np.array_equal(_batch(pt, flat, g, tw, ws, True, 128), np.array([[412, 832], [1, 1772]], np.int32))
     # every compiled l=65 variant gives the same positions
-    for v in (10, 11, 12, 13, 14, 2, 100):
+    for v in (10, 11, 12, 13, 14, 2, 100, 200):
         assert np.array_equal(_batch(pt, frames, guesses, tw, ws, True, fill, variant=v), got), v
     # noisy frames: a sample of windows against the dense Float64 oracle (279 M MAC each)
     nf, ng, _ = synth.make_batch(4, 1080, 1920, tw, radii, True, seed=12, noise=3)
