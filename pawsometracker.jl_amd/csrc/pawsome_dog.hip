@@ -124,6 +124,10 @@ struct pdog_tracker {
     int *d_dc = nullptr;
     int dc_cap = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // side stream + fork/join events: the thin-remainder kernel runs beside the strips (its waves fit in
+    // the registers the 2-waves-per-SIMD roll kernel leaves free) instead of after them
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     f2 *d_taps_row = nullptr, *d_taps_col = nullptr;
     f2 *d_taps_roll = nullptr; // paired column-tap table of dog_roll.hpp
     float *d_part_val = nullptr;
@@ -299,15 +303,20 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         return PDOG_OK;
     }
     const int grid = round_up(g.nblocks, 8);
+    if (t->nthin) {
+        // fork: the thin kernel only reads the frames and writes its own partial slots
+        HIP_TRY(hipEventRecord(t->ev_fork, t->stream));
+        HIP_TRY(hipStreamWaitEvent(t->aux_stream, t->ev_fork, 0));
+        const size_t thin_lds = sizeof(f2) * (size_t)(t->n1 + t->L - 1);
+        hipLaunchKernelGGL(d_out_resp ? v.thin_resp : v.thin, dim3(n * t->nthin), dim3(256), thin_lds, t->aux_stream, g,
+                           (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(t->ev_join, t->aux_stream));
+    }
     hipLaunchKernelGGL(d_out_resp ? v.fn_resp : v.fn, dim3(grid), dim3(v.NT), v.lds(t->L), t->stream, g,
                        (const f2 *)t->d_taps_row, (const f2 *)(v.roll ? t->d_taps_roll : t->d_taps_col));
     HIP_TRY(hipGetLastError());
-    if (t->nthin) {
-        const size_t thin_lds = sizeof(f2) * (size_t)(t->n1 + t->L - 1);
-        hipLaunchKernelGGL(d_out_resp ? v.thin_resp : v.thin, dim3(n * t->nthin), dim3(256), thin_lds, t->stream, g,
-                           (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
-        HIP_TRY(hipGetLastError());
-    }
+    if (t->nthin) HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0)); // join before the strip combine
     hipLaunchKernelGGL(dog_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, t->stream,
                        t->d_part_val, t->d_part_idx, d_guesses, d_out_ij, n, g.nslots,
                        t->r1, t->r2, t->n1, t->fh, t->fw);
@@ -412,6 +421,9 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
     } while (0)
     CREATE_TRY(hipStreamCreateWithFlags(&t->own_stream, hipStreamNonBlocking));
     t->stream = t->own_stream;
+    CREATE_TRY(hipStreamCreateWithFlags(&t->aux_stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
     CREATE_TRY(hipMalloc(&t->d_taps_row, sizeof(f2) * t->L));
     CREATE_TRY(hipMalloc(&t->d_taps_col, sizeof(f2) * t->L));
     CREATE_TRY(hipMemcpy(t->d_taps_row, tr.data(), sizeof(f2) * t->L, hipMemcpyHostToDevice));
@@ -457,6 +469,9 @@ int pdog_destroy(pdog_tracker *t)
     if (t->d_resp) (void)hipFree(t->d_resp);
     if (t->d_V) (void)hipFree(t->d_V);
     if (t->d_dc) (void)hipFree(t->d_dc);
+    if (t->aux_stream) { (void)hipStreamSynchronize(t->aux_stream); (void)hipStreamDestroy(t->aux_stream); }
+    if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
+    if (t->ev_join) (void)hipEventDestroy(t->ev_join);
     if (t->own_stream) (void)hipStreamDestroy(t->own_stream);
     delete t;
     return PDOG_OK;
