@@ -166,23 +166,34 @@ __host__ __device__ constexpr int roll_col_table_len(int L) { return roll_col_bl
 // Loop order (tap block, row, channel): every output receives its terms as t = 0: (+,−), 1: (+,−), …
 // whatever its alignment to blocks and sub-chunks, so equal inputs give bit-equal outputs.
 template <int L, int SC>
-__device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], const f2 (&rv)[ROLL_CH], tap_ptr table)
+__device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], const f2 (&rv)[ROLL_CH], tap_ptr table,
+                                              int t_lo, int t_hi)
 {
     constexpr int S = roll_slots(L), CH = ROLL_CH, QB = ROLL_QB, NQB = roll_col_blocks(L);
     static_assert(S % 2 == 0 && (CH * SC) % 2 == 0, "pairing needs even slot counts");
+    // block qb holds taps 2·QB·qb − 1 … 2·QB·(qb+1) − 1
+    auto needed = [&](int qb) { return 2 * QB * (qb + 1) - 1 >= t_lo && 2 * QB * qb - 1 <= t_hi; };
     f2 tn[4 * QB];
+    if (needed(0)) {
 #pragma unroll
-    for (int j = 0; j < 4 * QB; ++j) tn[j] = table[j];
+        for (int j = 0; j < 4 * QB; ++j) tn[j] = table[j];
+    }
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
         f2 t[4 * QB];
 #pragma unroll
         for (int j = 0; j < 4 * QB; ++j) t[j] = tn[j];
-        if (qb + 1 < NQB) {
+        // the next block's taps are requested only if that block will run: a skipped block must not
+        // leave a scalar load behind for its successor to wait on
+        if (qb + 1 < NQB && needed(qb + 1)) {
             const tap_ptr tnext = pin_taps(table + (qb + 1) * 4 * QB);
 #pragma unroll
             for (int j = 0; j < 4 * QB; ++j) tn[j] = tnext[j];
         }
+        // Taps outside [t_lo, t_hi] would only feed outputs above or below the window (the first and
+        // last l−1 input rows each see a shrinking part of the kernel): skip such blocks — wave-uniform,
+        // ≈19 % of the column-pass FMAs on a 257-row window.
+        if (needed(qb)) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int par = i & 1;
@@ -208,6 +219,7 @@ __device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], con
                 const int tt = (i & 1) + 2 * (QB * qb + m);
                 if (tt - 1 <= L - 1) pin_acc(acc2[(((CH * SC + i - tt) % S + S) % S) / 2]);
             }
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -344,7 +356,7 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         const int phase = sc % NBODY;
         auto emit = [&](auto SCc) {
             constexpr int SC = decltype(SCc)::value;
-            if (!(ABL & 1)) roll_col_body<L, SC>(acc2, rv, tcol);
+            if (!(ABL & 1)) roll_col_body<L, SC>(acc2, rv, tcol, max(0, sc * CH - (g.n1 - 1)), min(L - 1, sc * CH + CH - 1));
             // outputs y = a − (l−1) for the 8 rows of this sub-chunk are complete.  A lane owns ONE
             // column and meets its rows in increasing y (= increasing column-major index), so a strict
             // '>' keeps the first maximum of the lane (findmax, :59); ties between lanes and strips

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -313,7 +314,14 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(t->ev_join, t->aux_stream));
     }
-    hipLaunchKernelGGL(d_out_resp ? v.fn_resp : v.fn, dim3(grid), dim3(v.NT), v.lds(t->L), t->stream, g,
+    size_t lds_bytes = v.lds(t->L);
+#ifdef PDOG_ABLATIONS
+    if (const char *e = std::getenv("PDOG_LDS_PAD")) { // occupancy experiments: extra LDS per workgroup
+        lds_bytes += (size_t)std::atoi(e);
+        (void)hipFuncSetAttribute((const void *)(d_out_resp ? v.fn_resp : v.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    }
+#endif
+    hipLaunchKernelGGL(d_out_resp ? v.fn_resp : v.fn, dim3(grid), dim3(v.NT), lds_bytes, t->stream, g,
                        (const f2 *)t->d_taps_row, (const f2 *)(v.roll ? t->d_taps_roll : t->d_taps_col));
     HIP_TRY(hipGetLastError());
     if (t->nthin) HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0)); // join before the strip combine
