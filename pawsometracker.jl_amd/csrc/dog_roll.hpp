@@ -317,6 +317,18 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
     const int rr = lane & 7, rgx = lane >> 3; // row-pass task: row rr, output group rgx
     const long long resp_base = (long long)b * g.n1 * g.n2;
 
+    unsigned long long ph_stage = 0, ph_row = 0, ph_col = 0, ph_t = 0;
+    if (ABL & 32) ph_t = __builtin_amdgcn_s_memtime();
+    auto lap = [&](unsigned long long &bucket) {
+        if (ABL & 32) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory"); // charge outstanding memory to the phase that issued it
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            bucket += now - ph_t;
+            ph_t = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     for (int sc = 0; sc < nsub; ++sc) {
         // ---- stage this sub-chunk from the prefetched registers, request the next ----
         if (!(ABL & 4)) {
@@ -333,6 +345,7 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_barrier(); // single-wave workgroup: orders the LDS writes before the reads below
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        lap(ph_stage);
         // ---- row pass: rounds of 8 rows × 8 groups of 8 outputs ----
         if (!(ABL & 2)) {
 #pragma unroll 1
@@ -349,6 +362,7 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        lap(ph_row);
         // ---- column pass: 8 new R rows into the rolling accumulators ----
         f2 rv[CH];
 #pragma unroll
@@ -393,6 +407,11 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         default: emit(std::integral_constant<int, 8 % NBODY>{}); break;
         }
         __builtin_amdgcn_s_barrier(); // A / Rb are rewritten by the next sub-chunk
+        lap(ph_col);
+    }
+    if ((ABL & 32) && lane == 0 && g.resp) {
+        g.resp[4 * logical] = (float)ph_stage; g.resp[4 * logical + 1] = (float)ph_row;
+        g.resp[4 * logical + 2] = (float)ph_col; g.resp[4 * logical + 3] = (float)nsub;
     }
 
     if (ABL & 16) { // diagnostic build only: shader cycles and 100 MHz ticks of the main loop, per wave
