@@ -166,34 +166,23 @@ __host__ __device__ constexpr int roll_col_table_len(int L) { return roll_col_bl
 // Loop order (tap block, row, channel): every output receives its terms as t = 0: (+,−), 1: (+,−), …
 // whatever its alignment to blocks and sub-chunks, so equal inputs give bit-equal outputs.
 template <int L, int SC>
-__device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], const f2 (&rv)[ROLL_CH], tap_ptr table,
-                                              int t_lo, int t_hi)
+__device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], const f2 (&rv)[ROLL_CH], tap_ptr table)
 {
     constexpr int S = roll_slots(L), CH = ROLL_CH, QB = ROLL_QB, NQB = roll_col_blocks(L);
     static_assert(S % 2 == 0 && (CH * SC) % 2 == 0, "pairing needs even slot counts");
-    // block qb holds taps 2·QB·qb − 1 … 2·QB·(qb+1) − 1
-    auto needed = [&](int qb) { return 2 * QB * (qb + 1) - 1 >= t_lo && 2 * QB * qb - 1 <= t_hi; };
     f2 tn[4 * QB];
-    if (needed(0)) {
 #pragma unroll
-        for (int j = 0; j < 4 * QB; ++j) tn[j] = table[j];
-    }
+    for (int j = 0; j < 4 * QB; ++j) tn[j] = table[j];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
         f2 t[4 * QB];
 #pragma unroll
         for (int j = 0; j < 4 * QB; ++j) t[j] = tn[j];
-        // the next block's taps are requested only if that block will run: a skipped block must not
-        // leave a scalar load behind for its successor to wait on
-        if (qb + 1 < NQB && needed(qb + 1)) {
+        if (qb + 1 < NQB) {
             const tap_ptr tnext = pin_taps(table + (qb + 1) * 4 * QB);
 #pragma unroll
             for (int j = 0; j < 4 * QB; ++j) tn[j] = tnext[j];
         }
-        // Taps outside [t_lo, t_hi] would only feed outputs above or below the window (the first and
-        // last l−1 input rows each see a shrinking part of the kernel): skip such blocks — wave-uniform,
-        // ≈19 % of the column-pass FMAs on a 257-row window.
-        if (needed(qb)) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int par = i & 1;
@@ -219,7 +208,6 @@ __device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], con
                 const int tt = (i & 1) + 2 * (QB * qb + m);
                 if (tt - 1 <= L - 1) pin_acc(acc2[(((CH * SC + i - tt) % S + S) % S) / 2]);
             }
-        }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -317,18 +305,6 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
     const int rr = lane & 7, rgx = lane >> 3; // row-pass task: row rr, output group rgx
     const long long resp_base = (long long)b * g.n1 * g.n2;
 
-    unsigned long long ph_stage = 0, ph_row = 0, ph_col = 0, ph_t = 0;
-    if (ABL & 32) ph_t = __builtin_amdgcn_s_memtime();
-    auto lap = [&](unsigned long long &bucket) {
-        if (ABL & 32) {
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory"); // charge outstanding memory to the phase that issued it
-            const unsigned long long now = __builtin_amdgcn_s_memtime();
-            bucket += now - ph_t;
-            ph_t = now;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
     for (int sc = 0; sc < nsub; ++sc) {
         // ---- stage this sub-chunk from the prefetched registers, request the next ----
         if (!(ABL & 4)) {
@@ -345,7 +321,6 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_barrier(); // single-wave workgroup: orders the LDS writes before the reads below
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        lap(ph_stage);
         // ---- row pass: rounds of 8 rows × 8 groups of 8 outputs ----
         if (!(ABL & 2)) {
 #pragma unroll 1
@@ -362,7 +337,6 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        lap(ph_row);
         // ---- column pass: 8 new R rows into the rolling accumulators ----
         f2 rv[CH];
 #pragma unroll
@@ -370,7 +344,7 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         const int phase = sc % NBODY;
         auto emit = [&](auto SCc) {
             constexpr int SC = decltype(SCc)::value;
-            if (!(ABL & 1)) roll_col_body<L, SC>(acc2, rv, tcol, max(0, sc * CH - (g.n1 - 1)), min(L - 1, sc * CH + CH - 1));
+            if (!(ABL & 1)) roll_col_body<L, SC>(acc2, rv, tcol);
             // outputs y = a − (l−1) for the 8 rows of this sub-chunk are complete.  A lane owns ONE
             // column and meets its rows in increasing y (= increasing column-major index), so a strict
             // '>' keeps the first maximum of the lane (findmax, :59); ties between lanes and strips
@@ -407,11 +381,6 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         default: emit(std::integral_constant<int, 8 % NBODY>{}); break;
         }
         __builtin_amdgcn_s_barrier(); // A / Rb are rewritten by the next sub-chunk
-        lap(ph_col);
-    }
-    if ((ABL & 32) && lane == 0 && g.resp) {
-        g.resp[4 * logical] = (float)ph_stage; g.resp[4 * logical + 1] = (float)ph_row;
-        g.resp[4 * logical + 2] = (float)ph_col; g.resp[4 * logical + 3] = (float)nsub;
     }
 
     if (ABL & 16) { // diagnostic build only: shader cycles and 100 MHz ticks of the main loop, per wave

@@ -95,7 +95,6 @@ const Variant kVariants[] = {
     Variant { 104, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 12>, (kernel_fn)dog_roll_kernel<65, true>, true, nullptr, nullptr },
     Variant { 105, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 15>, (kernel_fn)dog_roll_kernel<65, true>, true, nullptr, nullptr },
     Variant { 106, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 0>, (kernel_fn)dog_roll_kernel<65, false, 16>, true, nullptr, nullptr },
-    Variant { 107, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 0>, (kernel_fn)dog_roll_kernel<65, false, 32>, true, nullptr, nullptr },
 #endif
     // l = 29 (target_width 10, the reference test default)
     PDOG_VARIANT(20, 8, 8, 4, 32, 29, 256),
