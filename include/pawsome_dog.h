@@ -125,6 +125,14 @@ int pdog_detect_chain(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_st
                       int64_t row_stride, int n_frames, const int32_t start_guess[2],
                       int32_t *d_out_ij);
 
+/* Many clips at once, each the serial chain of :163-169: clip c's frame k is frame c*n_frames + k of
+ * d_frames; d_start_guesses is n_clips x 2 (device), d_out_ij is n_clips x n_frames x 2 (device).
+ * For short kernels (l = 65) and windows up to 512 columns this is ONE persistent launch: a workgroup
+ * per clip walks its frames without any host involvement. */
+int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
+                       int64_t row_stride, int n_frames, int n_clips,
+                       const int32_t *d_start_guesses, int32_t *d_out_ij);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,20 @@ class BatchTracker:
                                                 frames.stride(1), n, g, C.c_void_p(out.data_ptr())))
         return out
 
+    def detect_chains(self, frames, start_guesses, out=None):
+        """Many clips at once (one persistent launch for l = 65): frames uint8 cuda [n_clips, n_frames, h, w],
+        start_guesses int32 cuda [n_clips, 2]; returns int32 cuda [n_clips, n_frames, 2]."""
+        import torch
+        assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4 and frames.stride(3) == 1
+        assert frames.stride(0) == frames.shape[1] * frames.stride(1), "clips must be stacked contiguously"
+        assert start_guesses.is_cuda and start_guesses.dtype == torch.int32 and start_guesses.is_contiguous()
+        nc, nf = frames.shape[0], frames.shape[1]
+        if out is None:
+            out = torch.empty((nc, nf, 2), dtype=torch.int32, device=frames.device)
+        _lib.check(_lib.lib().pdog_detect_chains(self._h, C.c_void_p(frames.data_ptr()), frames.stride(1), frames.stride(2),
+                                                 nf, nc, C.c_void_p(start_guesses.data_ptr()), C.c_void_p(out.data_ptr())))
+        return out
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.lib().pdog_destroy(self._h)

@@ -215,9 +215,12 @@ __device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], con
 
 // ABL: timing-only ablation bits (tools/tune): 1 = no column FMAs, 2 = no row pass, 4 = no staging
 // conversion/LDS writes, 8 = no global loads.  ABL != 0 gives wrong results by design.
-template <int LT, bool RESP, int ABL = 0>
-__global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, const f2 *__restrict__ taps_row,
-                                                         const f2 *__restrict__ taps_col)
+// One strip of one window, executed by ONE wave with wave-private LDS at `smem`: everything from the DC
+// level to the wave-level peak reduction.  (best, best_idx) are valid in lane 0 on return.
+template <int LT, bool RESP, int ABL>
+__device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restrict__ taps_row, const f2 *__restrict__ taps_col,
+                                           unsigned char *smem, const uint8_t *__restrict__ frame, int g1, int g2, int s,
+                                           int b, int logical, float &best_out, int &best_idx_out)
 {
     constexpr int L = LT, hw = L / 2, S = roll_slots(L), CH = ROLL_CH, P = ROLL_P, TW = ROLL_TW;
     constexpr int NBODY = S / CH;
@@ -228,20 +231,10 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
     static_assert(TWin == 128 && (SB == 16 || SB == 32), "staging assumes 16 or 32 B per lane");
     constexpr int RPASS = CH / 8;      // row-pass rounds: 8 rows × 8 groups of P = 8 outputs per round
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *A = reinterpret_cast<float *>(smem);
     f2 *Rb = reinterpret_cast<f2 *>(smem + CH * ROLL_PA * 4);
 
-    const int per_xcd = (g.nblocks + 7) >> 3;
-    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (logical >= g.nblocks) return;
-    const int b = logical / g.nstrips;
-    const int s = logical - b * g.nstrips;
-    const int lane = threadIdx.x;
-
-    const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
-    const int fidx = g.frame_index ? g.frame_index[b] : b;
-    const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
+    const int lane = threadIdx.x & 63;
     // strips are 64 wide; the last one is shifted left to stay inside the window (overlap
     // recomputes a few columns bit-identically), or is partial when the window is < 64 wide
     const int ncols = g.nthin ? g.thin_x0 : g.n2; // columns covered by 64-wide strips
@@ -319,7 +312,7 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
             if (!(ABL & 8)) load16((sc + 1) * CH + srow, pre);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_barrier(); // single-wave workgroup: orders the LDS writes before the reads below
+        __builtin_amdgcn_wave_barrier(); // the LDS traffic is wave-private: the fences' waits are all the ordering needed
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // ---- row pass: rounds of 8 rows × 8 groups of 8 outputs ----
         if (!(ABL & 2)) {
@@ -335,7 +328,7 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // ---- column pass: 8 new R rows into the rolling accumulators ----
         f2 rv[CH];
@@ -380,7 +373,7 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         case 7: emit(std::integral_constant<int, 7 % NBODY>{}); break;
         default: emit(std::integral_constant<int, 8 % NBODY>{}); break;
         }
-        __builtin_amdgcn_s_barrier(); // A / Rb are rewritten by the next sub-chunk
+        __builtin_amdgcn_wave_barrier(); // A / Rb are rewritten by the next sub-chunk
     }
 
     if (ABL & 16) { // diagnostic build only: shader cycles and 100 MHz ticks of the main loop, per wave
@@ -395,9 +388,79 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
         const int oi = __shfl_down(best_idx, off, 64);
         if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
     }
-    if (lane == 0) {
+    best_out = best;       // valid in lane 0
+    best_idx_out = best_idx;
+}
+
+
+template <int LT, bool RESP, int ABL = 0>
+__global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, const f2 *__restrict__ taps_row,
+                                                         const f2 *__restrict__ taps_col)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // XCD-aware block → (window, strip), see dog_kernels.hpp
+    const int per_xcd = (g.nblocks + 7) >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= g.nblocks) return;
+    const int b = logical / g.nstrips;
+    const int s = logical - b * g.nstrips;
+    const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
+    const int fidx = g.frame_index ? g.frame_index[b] : b;
+    const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
+    float best;
+    int best_idx;
+    roll_strip<LT, RESP, ABL>(g, taps_row, taps_col, smem, frame, g1, g2, s, b, logical, best, best_idx);
+    if (threadIdx.x == 0) {
         g.part_val[b * g.nslots + s] = best;
         g.part_idx[b * g.nslots + s] = best_idx;
+    }
+}
+
+// ---- persistent serial chain (src/PawsomeTracker.jl:163-169, the intended loop :167) ----
+// One workgroup per clip, one wave per strip of the search window; the workgroup walks the clip's frames,
+// each frame searched around the previous frame's clamped answer, with no host round trip and no launch
+// per frame.  Strips meet through 2 LDS words per wave and one workgroup barrier per frame.  Thin remainder
+// columns are not used here: the last strip overlaps instead (bit-identical values either way).
+struct ChainGeo {
+    LaunchGeo g;                         // frames = first frame of clip 0; guesses/frame_index unused
+    const int *__restrict__ start;       // n_clips x 2, 1-based (row, col)
+    int *__restrict__ out_ij;            // n_clips x n_frames x 2
+    int n_frames;                        // per clip; clip c's frame k is frame c*n_frames + k
+};
+template <int LT>
+__global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const f2 *__restrict__ taps_row,
+                                                        const f2 *__restrict__ taps_col)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int cur[2];
+    __shared__ float pv[8];
+    __shared__ int pi[8];
+    const LaunchGeo &g = cg.g;
+    const int tid = threadIdx.x, wave = tid >> 6, nst = blockDim.x >> 6;
+    const int c = blockIdx.x;
+    if (tid == 0) { cur[0] = cg.start[2 * c]; cur[1] = cg.start[2 * c + 1]; }
+    __syncthreads();
+    for (int k = 0; k < cg.n_frames; ++k) {
+        const int g1 = cur[0], g2 = cur[1];
+        const uint8_t *__restrict__ frame = g.frames + ((long long)c * cg.n_frames + k) * g.frame_stride;
+        float best;
+        int best_idx;
+        roll_strip<LT, false, 0>(g, taps_row, taps_col, smem + wave * roll_lds_bytes(), frame, g1, g2, wave, 0, 0, best, best_idx);
+        if ((tid & 63) == 0) { pv[wave] = best; pi[wave] = best_idx; }
+        __syncthreads();
+        if (tid == 0) {
+            float bv = pv[0];
+            int bi = pi[0];
+            for (int w = 1; w < nst; ++w)
+                if (pv[w] > bv || (pv[w] == bv && pi[w] < bi)) { bv = pv[w]; bi = pi[w]; }
+            const int x = bi / g.n1, y = bi - x * g.n1;
+            const int i = min(max(g1 - g.r1 + y, 1), g.fh);   // :60-61
+            const int j = min(max(g2 - g.r2 + x, 1), g.fw);
+            int *o = cg.out_ij + 2 * ((long long)c * cg.n_frames + k);
+            o[0] = i; o[1] = j;
+            cur[0] = i; cur[1] = j;
+        }
+        __syncthreads();
     }
 }
 

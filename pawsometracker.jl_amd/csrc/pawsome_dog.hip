@@ -594,17 +594,17 @@ int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride
     return PDOG_OK;
 }
 
-int pdog_detect_chain(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
-                      int n_frames, const int32_t start_guess[2], int32_t *d_out_ij)
+} // extern "C" (first part)
+
+namespace {
+
+// stream-ordered fallback: frame k's guess is frame k-1's (clamped) answer, read straight from the
+// output array — stream order is the dependency, no host round trip per frame
+int chain_by_launches(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
+                      int n_frames, const int32_t *d_start, int32_t *d_out_ij)
 {
-    if (!t || !d_frames || !start_guess || !d_out_ij) return fail(PDOG_E_ARG, "pdog_detect_chain: null pointer");
-    if (n_frames <= 0 || row_stride < t->fw) return fail(PDOG_E_ARG, "pdog_detect_chain: bad size/stride");
-    HIP_TRY(hipSetDevice(t->device));
-    HIP_TRY(hipMemcpyAsync(t->d_small, start_guess, sizeof(int32_t) * 2, hipMemcpyHostToDevice, t->stream));
-    // frame k's guess is frame k-1's (clamped) answer, read straight from the output array:
-    // stream order is the dependency, no host round-trip per frame.
     for (int k = 0; k < n_frames; ++k) {
-        const int32_t *guess = k ? d_out_ij + 2 * (k - 1) : t->d_small;
+        const int32_t *guess = k ? d_out_ij + 2 * (k - 1) : d_start;
         int rc = launch_detect(t, d_frames + (int64_t)k * frame_stride, frame_stride, row_stride, nullptr, guess, 1,
                                d_out_ij + 2 * k, nullptr);
         if (rc) return rc;
@@ -612,4 +612,56 @@ int pdog_detect_chain(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_st
     return PDOG_OK;
 }
 
+} // namespace
+
+extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
+                                  int n_frames, int n_clips, const int32_t *d_start_guesses, int32_t *d_out_ij)
+{
+    if (!t || !d_frames || !d_start_guesses || !d_out_ij) return fail(PDOG_E_ARG, "pdog_detect_chains: null pointer");
+    if (n_frames <= 0 || n_clips <= 0 || row_stride < t->fw || frame_stride < 0)
+        return fail(PDOG_E_ARG, "pdog_detect_chains: bad size/stride");
+    HIP_TRY(hipSetDevice(t->device));
+    const Variant &v = *t->var;
+    const int chain_strips = (t->n2 + ROLL_TW - 1) / ROLL_TW;
+    if (v.roll && v.LT == 65 && chain_strips <= 8) {
+        ChainGeo cg;
+        LaunchGeo &g = cg.g;
+        std::memset(&g, 0, sizeof g);
+        g.frames = d_frames;
+        g.frame_stride = frame_stride;
+        g.row_stride = row_stride;
+        g.fh = t->fh; g.fw = t->fw; g.r1 = t->r1; g.r2 = t->r2; g.n1 = t->n1; g.n2 = t->n2;
+        g.L = t->L; g.fill = t->fill; g.nstrips = chain_strips; g.n = n_clips;
+        g.nblocks = n_clips * chain_strips;
+        g.nslots = chain_strips;
+        cg.start = d_start_guesses;
+        cg.out_ij = d_out_ij;
+        cg.n_frames = n_frames;
+        const size_t lds = (size_t)chain_strips * roll_lds_bytes();
+        HIP_TRY(hipFuncSetAttribute((const void *)dog_chain_kernel<65>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(dog_chain_kernel<65>, dim3(n_clips), dim3(64 * chain_strips), lds, t->stream, cg,
+                           (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_roll);
+        HIP_TRY(hipGetLastError());
+        return PDOG_OK;
+    }
+    if (t->cap_windows < 1) { int rc = ensure_capacity(t, 1); if (rc) return rc; }
+    for (int c = 0; c < n_clips; ++c) {
+        int rc = chain_by_launches(t, d_frames + (int64_t)c * n_frames * frame_stride, frame_stride, row_stride, n_frames,
+                                   d_start_guesses + 2 * c, d_out_ij + 2 * (int64_t)c * n_frames);
+        if (rc) return rc;
+    }
+    return PDOG_OK;
+}
+
+extern "C" int pdog_detect_chain(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
+                                 int n_frames, const int32_t start_guess[2], int32_t *d_out_ij)
+{
+    if (!t || !d_frames || !start_guess || !d_out_ij) return fail(PDOG_E_ARG, "pdog_detect_chain: null pointer");
+    if (n_frames <= 0 || row_stride < t->fw) return fail(PDOG_E_ARG, "pdog_detect_chain: bad size/stride");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipMemcpyAsync(t->d_small, start_guess, sizeof(int32_t) * 2, hipMemcpyHostToDevice, t->stream));
+    return pdog_detect_chains(t, d_frames, frame_stride, row_stride, n_frames, 1, t->d_small, d_out_ij);
+}
+
+extern "C" {
 } // extern "C"

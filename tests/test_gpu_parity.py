@@ -258,3 +258,38 @@ def test_random_geometries_vs_oracle(pt, oracle):
         _check_resp(resp, ref, f"rand tw={tw} win=({wh},{ww}) frame=({h},{w})")
         assert t(guess) == ref_ij
         t.close()
+
+
+def test_persistent_multi_clip_chains(pt, oracle):
+    """pdog_detect_chains: several clips, each the serial chain of :163-169, in one persistent launch
+    (one wave per strip, one workgroup per clip) — against the oracle's chain, for a one-strip and a
+    multi-strip search window (the latter covers the overlapping last strip and the LDS exchange)."""
+    import torch
+    from oracle import synth
+    from oracle.dog_oracle import OracleTracker
+    rng = np.random.default_rng(11)
+    for (h, w, tw, ws, nclips, nf) in ((120, 160, 25, (45, 45), 3, 12), (200, 260, 25, (90, 150), 2, 6)):
+        clips, starts, refs = [], [], []
+        for c in range(nclips):
+            pos = np.cumsum(rng.integers(-5, 6, (nf, 2)), 0) + np.array([h // 2, w // 2])
+            pos = np.clip(pos, 15, [h - 15, w - 15])
+            fr = np.stack([synth.disc_frame(h, w, (int(p[0]), int(p[1])), tw, True) for p in pos])
+            fr = np.clip(fr.astype(np.int16) + rng.integers(-3, 4, fr.shape), 0, 255).astype(np.uint8)
+            clips.append(fr)
+            starts.append((int(pos[0][0]) + 3, int(pos[0][1]) - 4))
+        fill = oracle.mode_u8(clips[0][0])
+        for c in range(nclips):
+            ot = OracleTracker(clips[c][0], tw, ws, True, oracle)
+            ot.fill = fill
+            r = [ot(starts[c])]
+            for f in clips[c][1:]:
+                ot.data[...] = f
+                r.append(ot(r[-1]))
+            refs.append(r)
+        bt = pt.BatchTracker(h, w, tw, ws, True, fill)
+        out = bt.detect_chains(torch.from_numpy(np.stack(clips)).cuda(), torch.tensor(starts, dtype=torch.int32).cuda())
+        bt.sync()
+        got = out.cpu().numpy()
+        for c in range(nclips):
+            assert [tuple(int(v) for v in r) for r in got[c]] == refs[c], (ws, c)
+        bt.close()
