@@ -35,11 +35,16 @@ namespace pdog {
 constexpr int ROLL_CH = 8;   // rows per sub-chunk (16 measured equal on cfg3: the kernel is VALU-bound, not latency-bound)
 constexpr int ROLL_P = 8;    // row-pass outputs per lane
 constexpr int ROLL_TW = 64;  // strip width = lanes
-constexpr int ROLL_PA = 129; // A pitch (f32): odd → conflict-free row-pass reads
 constexpr int ROLL_PR = 65;  // R pitch (f2)
+constexpr int ROLL_LMIN = 17, ROLL_LMAX = 77; // kernel lengths with a roll instance (l = 4m+1)
 
-__host__ __device__ constexpr int roll_slots(int L) { return L - 1 + ROLL_CH; }
-__host__ __device__ constexpr size_t roll_lds_bytes() { return (size_t)ROLL_CH * ROLL_PA * 4 + (size_t)ROLL_CH * ROLL_PR * 8; }
+// accumulator slots: the l outputs in flight plus the sub-chunk being emitted, rounded so that the
+// slot ↔ tap mapping repeats after a whole number of sub-chunks
+__host__ __device__ constexpr int roll_slots(int L) { return (L - 1 + ROLL_CH + ROLL_CH - 1) / ROLL_CH * ROLL_CH; }
+// staging: 8 lanes per input row, each SB (multiple of 4) bytes; A pitch odd → conflict-free row-pass reads
+__host__ __device__ constexpr int roll_sb(int L) { return ((ROLL_TW + L - 1 + 7) / 8 + 3) / 4 * 4; }
+__host__ __device__ constexpr int roll_pa(int L) { return (8 * roll_sb(L)) | 1; }
+__host__ __device__ constexpr size_t roll_lds_bytes(int L) { return (size_t)ROLL_CH * roll_pa(L) * 4 + (size_t)ROLL_CH * ROLL_PR * 8; }
 
 // The fixed 32×32 sample grid over the window's padded tile that decides the DC level (see
 // dog_kernels.hpp): thread `tid` of `nthreads` adds up its share; callers reduce and finish.
@@ -91,7 +96,6 @@ __device__ __forceinline__ void roll_row_pass(f2 (&acc)[ROLL_P], const float *a,
 {
     constexpr int P = ROLL_P, H = L / 2, U = 4, NP = P / 2;
     constexpr int W = 2 * (NP - 1) + U; // pairs per window: n = base + (2*op + u)
-    static_assert(H % U == 0, "half length must be a multiple of the tap block");
     auto pair_at = [&](int n) { return f2{a[n], a[n + 1]}; };
     f2 lo[W], hi[W];
 #pragma unroll
@@ -104,15 +108,17 @@ __device__ __forceinline__ void roll_row_pass(f2 (&acc)[ROLL_P], const float *a,
     for (int j = 0; j < U; ++j) tn[j] = taps[j];
 #pragma unroll
     for (int k0 = 0; k0 < H; k0 += U) {
+        const int nu = (H - k0 < U) ? (H - k0) : U; // the last block is partial when H is not a multiple of U
+        const bool more = (k0 + U < H);
         f2 t[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) t[j] = tn[j];
         f2 nlo[U], nhi[U];
-        const tap_ptr tnext = pin_taps(taps + (k0 + U < H ? k0 + U : H));
-        if (k0 + U < H) {
+        const tap_ptr tnext = pin_taps(taps + (more ? k0 + U : H));
+        if (more) {
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                tn[j] = tnext[j];
+                tn[j] = tnext[j]; // may run past tap H−1 on the last full load: those entries are never used
                 nlo[j] = pair_at(k0 + U + (W - U) + j); // new upper end of the next lo window
                 nhi[j] = pair_at(L - U - (k0 + U) + j); // new lower end of the next hi window
             }
@@ -123,14 +129,16 @@ __device__ __forceinline__ void roll_row_pass(f2 (&acc)[ROLL_P], const float *a,
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            if (u < nu) {
 #pragma unroll
-            for (int op = 0; op < NP; ++op) {
-                const f2 s2 = lo[2 * op + u] + hi[2 * op + (U - 1) - u];
-                acc[2 * op] = fma_bcast(s2.x, t[u], acc[2 * op]);
-                acc[2 * op + 1] = fma_bcast(s2.y, t[u], acc[2 * op + 1]);
+                for (int op = 0; op < NP; ++op) {
+                    const f2 s2 = lo[2 * op + u] + hi[2 * op + (U - 1) - u];
+                    acc[2 * op] = fma_bcast(s2.x, t[u], acc[2 * op]);
+                    acc[2 * op + 1] = fma_bcast(s2.y, t[u], acc[2 * op + 1]);
+                }
             }
         }
-        if (k0 + U < H) {
+        if (more) {
 #pragma unroll
             for (int j = 0; j < W - U; ++j) lo[j] = lo[j + U];
 #pragma unroll
@@ -225,14 +233,14 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
     constexpr int L = LT, hw = L / 2, S = roll_slots(L), CH = ROLL_CH, P = ROLL_P, TW = ROLL_TW;
     constexpr int NBODY = S / CH;
     static_assert(S % CH == 0, "slot count must be a multiple of the sub-chunk");
-    constexpr int TWin = TW + L - 1; // 128 input columns
-    constexpr int SB = CH * TWin / 64; // staged bytes per lane per sub-chunk (16 or 32)
-    constexpr int SEGS = TWin / SB;    // lanes per row
-    static_assert(TWin == 128 && (SB == 16 || SB == 32), "staging assumes 16 or 32 B per lane");
+    static_assert(CH == 8 && L % 4 == 1 && L >= ROLL_LMIN && L <= ROLL_LMAX, "roll kernel instance out of range");
+    constexpr int SB = roll_sb(L);     // staged bytes per lane per sub-chunk (16 for l = 65)
+    constexpr int SEGS = 64 / CH;      // lanes per row
+    constexpr int PA = roll_pa(L);
     constexpr int RPASS = CH / 8;      // row-pass rounds: 8 rows × 8 groups of P = 8 outputs per round
 
     float *A = reinterpret_cast<float *>(smem);
-    f2 *Rb = reinterpret_cast<f2 *>(smem + CH * ROLL_PA * 4);
+    f2 *Rb = reinterpret_cast<f2 *>(smem + CH * PA * 4);
 
     const int lane = threadIdx.x & 63;
     // strips are 64 wide; the last one is shifted left to stay inside the window (overlap
@@ -301,7 +309,7 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
     for (int sc = 0; sc < nsub; ++sc) {
         // ---- stage this sub-chunk from the prefetched registers, request the next ----
         if (!(ABL & 4)) {
-            float *dst = A + srow * ROLL_PA + SB * sseg;
+            float *dst = A + srow * PA + SB * sseg;
             const float fdc = (float)dc;
 #pragma unroll
             for (int i = 0; i < SB; ++i) {
@@ -321,7 +329,7 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
                 f2 racc[P];
 #pragma unroll
                 for (int o = 0; o < P; ++o) racc[o] = f2{0.f, 0.f};
-                roll_row_pass<L>(racc, A + (rr + 8 * h) * ROLL_PA + rgx * P, trow);
+                roll_row_pass<L>(racc, A + (rr + 8 * h) * PA + rgx * P, trow);
                 f2 *dst = Rb + (rr + 8 * h) * ROLL_PR + rgx * P;
 #pragma unroll
                 for (int o = 0; o < P; ++o) dst[o] = racc[o];
@@ -361,7 +369,7 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
                 if (slot & 1) acc2[slot / 2].y = 0.f; else acc2[slot / 2].x = 0.f;
             }
         };
-        static_assert(NBODY <= 9, "extend the phase switch");
+        static_assert(NBODY <= 11, "extend the phase switch");
         switch (phase) {
         case 0: emit(std::integral_constant<int, 0>{}); break;
         case 1: emit(std::integral_constant<int, 1 % NBODY>{}); break;
@@ -371,7 +379,9 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
         case 5: emit(std::integral_constant<int, 5 % NBODY>{}); break;
         case 6: emit(std::integral_constant<int, 6 % NBODY>{}); break;
         case 7: emit(std::integral_constant<int, 7 % NBODY>{}); break;
-        default: emit(std::integral_constant<int, 8 % NBODY>{}); break;
+        case 8: emit(std::integral_constant<int, 8 % NBODY>{}); break;
+        case 9: emit(std::integral_constant<int, 9 % NBODY>{}); break;
+        default: emit(std::integral_constant<int, 10 % NBODY>{}); break;
         }
         __builtin_amdgcn_wave_barrier(); // A / Rb are rewritten by the next sub-chunk
     }
@@ -445,7 +455,7 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
         const uint8_t *__restrict__ frame = g.frames + ((long long)c * cg.n_frames + k) * g.frame_stride;
         float best;
         int best_idx;
-        roll_strip<LT, false, 0>(g, taps_row, taps_col, smem + wave * roll_lds_bytes(), frame, g1, g2, wave, 0, 0, best, best_idx);
+        roll_strip<LT, false, 0>(g, taps_row, taps_col, smem + wave * roll_lds_bytes(LT), frame, g1, g2, wave, 0, 0, best, best_idx);
         if ((tid & 63) == 0) { pv[wave] = best; pi[wave] = best_idx; }
         __syncthreads();
         if (tid == 0) {

@@ -56,13 +56,15 @@ struct Variant {
     bool roll;             // dog_roll.hpp (one wave per 64-column strip) instead of dog_kernels.hpp
     kernel_fn thin, thin_resp; // remainder-column kernel of the roll variants (may be null)
     int twopass = 0;           // dog_twopass.hpp: vertical pass → HBM → horizontal pass (Q = this value)
+    typedef void (*chain_fn)(const ChainGeo, const f2 *, const f2 *);
+    chain_fn chain = nullptr;  // persistent serial-chain kernel of the roll variants
     int tw() const { return P * XG; }
     int ring(int L) const { return LT ? ring_rows(CH, LT, Q) : ring_rows(CH, L, Q); }
     int pa(int L) const { return pitch_a(tw() + L - 1); }
     size_t lds(int L) const
     {
         if (twopass) return 0; // sized per window width at launch
-        if (roll) return roll_lds_bytes();
+        if (roll) return roll_lds_bytes(LT);
         return (size_t)round_up(CH * pa(L) * 4, 16) + (size_t)ring(L) * pitch_r(tw()) * sizeof(f2);
     }
 };
@@ -72,7 +74,7 @@ struct Variant {
 #define PDOG_ROLL_VARIANT(id, LT) \
     Variant { id, ROLL_P, ROLL_TW / ROLL_P, ROLL_CH, ROLL_CH, LT, 64, (kernel_fn)dog_roll_kernel<LT, false>, \
               (kernel_fn)dog_roll_kernel<LT, true>, true, (kernel_fn)dog_thin_kernel<LT, false>, \
-              (kernel_fn)dog_thin_kernel<LT, true> }
+              (kernel_fn)dog_thin_kernel<LT, true>, 0, dog_chain_kernel<LT> }
 
 const Variant kVariants[] = {
     // runtime-L (any target_width)
@@ -85,7 +87,11 @@ const Variant kVariants[] = {
     PDOG_VARIANT(12, 8, 8, 16, 32, 65, 256),
     PDOG_VARIANT(13, 8, 8, 8, 32, 65, 256),
     PDOG_VARIANT(14, 11, 8, 8, 32, 65, 256),
-    PDOG_ROLL_VARIANT(100, 65),
+    // rolling-accumulator kernel: one instance per kernel length l = 4m+1, 17 … 77 (target_width ≈ 5 … 30)
+    PDOG_ROLL_VARIANT(117, 17), PDOG_ROLL_VARIANT(121, 21), PDOG_ROLL_VARIANT(125, 25), PDOG_ROLL_VARIANT(129, 29),
+    PDOG_ROLL_VARIANT(133, 33), PDOG_ROLL_VARIANT(137, 37), PDOG_ROLL_VARIANT(141, 41), PDOG_ROLL_VARIANT(145, 45),
+    PDOG_ROLL_VARIANT(149, 49), PDOG_ROLL_VARIANT(153, 53), PDOG_ROLL_VARIANT(157, 57), PDOG_ROLL_VARIANT(161, 61),
+    PDOG_ROLL_VARIANT(100, 65), PDOG_ROLL_VARIANT(169, 69), PDOG_ROLL_VARIANT(173, 73), PDOG_ROLL_VARIANT(177, 77),
     // any l: two launches with the intermediate in HBM (long kernels, target_width ≳ 40)
     Variant { 200, 13, 16, 16, 16, 0, 256, nullptr, nullptr, false, nullptr, nullptr, 16 },
 #ifdef PDOG_ABLATIONS
@@ -623,7 +629,7 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
     HIP_TRY(hipSetDevice(t->device));
     const Variant &v = *t->var;
     const int chain_strips = (t->n2 + ROLL_TW - 1) / ROLL_TW;
-    if (v.roll && v.LT == 65 && chain_strips <= 8) {
+    if (v.roll && v.chain && chain_strips <= 8) {
         ChainGeo cg;
         LaunchGeo &g = cg.g;
         std::memset(&g, 0, sizeof g);
@@ -637,9 +643,9 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
         cg.start = d_start_guesses;
         cg.out_ij = d_out_ij;
         cg.n_frames = n_frames;
-        const size_t lds = (size_t)chain_strips * roll_lds_bytes();
-        HIP_TRY(hipFuncSetAttribute((const void *)dog_chain_kernel<65>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(dog_chain_kernel<65>, dim3(n_clips), dim3(64 * chain_strips), lds, t->stream, cg,
+        const size_t lds = (size_t)chain_strips * roll_lds_bytes(v.LT);
+        HIP_TRY(hipFuncSetAttribute((const void *)v.chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(v.chain, dim3(n_clips), dim3(64 * chain_strips), lds, t->stream, cg,
                            (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_roll);
         HIP_TRY(hipGetLastError());
         return PDOG_OK;

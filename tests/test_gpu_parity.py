@@ -242,6 +242,9 @@ def test_random_geometries_vs_oracle(pt, oracle):
         cases.append((25, int(rng.integers(3, 60)) | 1, wcols | 1))
     for _ in range(6):
         cases.append((int(rng.choice([10, 16, 25])), int(rng.integers(1, 90)) | 1, int(rng.integers(1, 150)) | 1))
+    # every roll-kernel instance (l = 17 … 77) plus a runtime-l length, on strip layouts with and without remainder
+    for tw in (5, 7, 8, 10, 12, 13, 15, 17, 18, 20, 22, 23, 25, 27, 28, 30, 33):
+        cases.append((tw, int(rng.integers(20, 80)) | 1, int(rng.choice([45, 64, 67, 131]))| 1))
     for tw, wh, ww in cases:
         h, w = int(rng.integers(40, 200)), int(rng.integers(60, 260))
         centre = (int(rng.integers(1, h + 1)), int(rng.integers(1, w + 1)))
@@ -268,7 +271,8 @@ def test_persistent_multi_clip_chains(pt, oracle):
     from oracle import synth
     from oracle.dog_oracle import OracleTracker
     rng = np.random.default_rng(11)
-    for (h, w, tw, ws, nclips, nf) in ((120, 160, 25, (45, 45), 3, 12), (200, 260, 25, (90, 150), 2, 6)):
+    for (h, w, tw, ws, nclips, nf) in ((120, 160, 25, (45, 45), 3, 12), (200, 260, 25, (90, 150), 2, 6), (100, 100, 10, (21, 21), 2, 10),
+                                        (150, 200, 40, (61, 61), 1, 4)):
         clips, starts, refs = [], [], []
         for c in range(nclips):
             pos = np.cumsum(rng.integers(-5, 6, (nf, 2)), 0) + np.array([h // 2, w // 2])
