@@ -297,3 +297,31 @@ def test_persistent_multi_clip_chains(pt, oracle):
         for c in range(nclips):
             assert [tuple(int(v) for v in r) for r in got[c]] == refs[c], (ws, c)
         bt.close()
+
+
+def test_extreme_parameters_do_not_break(pt, oracle):
+    """Unusual but legal parameters: tiny and huge target widths, windows larger than the frame,
+    one-pixel frames' worth of window, very wide windows — positions against the oracle where the
+    dense oracle is affordable, otherwise the known answers (flat -> window top-left clamped)."""
+    from oracle import synth
+    rng = np.random.default_rng(5)
+    # small enough for the dense oracle
+    for tw, ws, (h, w) in ((1, (5, 5), (40, 50)), (2, (9, 7), (40, 50)), (3, (11, 11), (30, 30)), (200, (9, 9), (64, 64)),
+                           (60, (31, 33), (90, 120)), (25, (3, 301), (60, 400)), (25, (201, 3), (300, 50))):
+        f = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        fill = oracle.mode_u8(f)
+        K = oracle.dog_kernel(oracle.sigma(tw), True)
+        guess = (int(rng.integers(1, h + 1)), int(rng.integers(1, w + 1)))
+        ref_ij, ref = oracle.detect(f, fill, K, (ws[0] // 2, ws[1] // 2), guess, want_resp=True)
+        t = pt.Tracker(f, tw, ws, True)
+        ij, resp = t(guess, want_resp=True)
+        assert ij == ref_ij, (tw, ws, ij, ref_ij, t.info().variant)
+        _check_resp(resp, ref, f"extreme tw={tw} ws={ws}")
+        t.close()
+    # too big for the dense oracle: flat frames have a known answer
+    flat = np.full((1080, 1920), 200, np.uint8)
+    for tw, ws, guess in ((25, (1001, 1921), (540, 960)), (120, (401, 401), (300, 300)), (25, (2161, 11), (10, 10))):
+        t = pt.Tracker(flat, tw, ws, True)
+        exp = (max(1, guess[0] - ws[0] // 2), max(1, guess[1] - ws[1] // 2))
+        assert t(guess) == exp, (tw, ws, t.info().variant)
+        t.close()
