@@ -33,7 +33,9 @@ class BatchTracker:
         _lib.check(_lib.lib().pdog_reserve(self._h, int(n)))
 
     def use_torch_stream(self):
-        """Launch on torch's current stream so torch events / graphs see the kernels."""
+        """Launch on torch's current stream.  Every detect* call does this: the kernels are asynchronous, and
+        only work queued on the stream torch's caching allocator knows about is safe against a tensor
+        (guesses, frames) being dropped by the caller and its memory reused before the kernels ran."""
         import torch
         _lib.check(_lib.lib().pdog_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
@@ -45,6 +47,7 @@ class BatchTracker:
         1-based (row, col).  Returns int32 cuda [n, 2] (and float32 [n, win_w, win_h] — each
         window column-major, i.e. resp[b].T is the h x w response — when want_resp)."""
         import torch
+        self.use_torch_stream()
         assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3
         assert frames.stride(2) == 1 and frames.shape[1] == self.frame_h and frames.shape[2] == self.frame_w
         assert guesses.is_cuda and guesses.dtype == torch.int32 and guesses.is_contiguous()
@@ -68,6 +71,7 @@ class BatchTracker:
     def detect_chain(self, frames, start_guess, out=None):
         """The serial chain of src/PawsomeTracker.jl:163-169 on device-resident frames."""
         import torch
+        self.use_torch_stream()
         assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3 and frames.stride(2) == 1
         n = frames.shape[0]
         if out is None:
@@ -81,6 +85,7 @@ class BatchTracker:
         """Many clips at once (one persistent launch for l = 65): frames uint8 cuda [n_clips, n_frames, h, w],
         start_guesses int32 cuda [n_clips, 2]; returns int32 cuda [n_clips, n_frames, 2]."""
         import torch
+        self.use_torch_stream()
         assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4 and frames.stride(3) == 1
         assert frames.stride(0) == frames.shape[1] * frames.stride(1), "clips must be stacked contiguously"
         assert start_guesses.is_cuda and start_guesses.dtype == torch.int32 and start_guesses.is_contiguous()

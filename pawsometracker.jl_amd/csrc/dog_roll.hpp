@@ -474,6 +474,20 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
     }
 }
 
+// Step of a multi-clip chain run as ordinary batches: file the step's answers under [clip][frame] and make
+// them the next step's guesses.
+__global__ void dog_chain_step_kernel(const int *__restrict__ step_ij, int *__restrict__ cur, int *__restrict__ out_ij,
+                                      int n_clips, int n_frames, int k)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_clips) return;
+    const int i = step_ij[2 * c], j = step_ij[2 * c + 1];
+    out_ij[2 * ((long long)c * n_frames + k)] = i;
+    out_ij[2 * ((long long)c * n_frames + k) + 1] = j;
+    cur[2 * c] = i;
+    cur[2 * c + 1] = j;
+}
+
 // ---- thin remainder ----
 // A window whose width is 64·k + r with small r (257 = 4·64 + 1) would need a whole extra strip for
 // r columns.  Instead those columns are done here, one 256-thread workgroup per (window, column):

@@ -125,6 +125,10 @@ struct pdog_tracker {
     const Variant *var = nullptr;
     int nstrips = 0;
     int nthin = 0, thin_x0 = 0; // window columns handled by the thin-remainder kernel
+    bool forced_variant = false;   // pdog_set_variant pinned the kernel: no batch-size switching
+    bool small_twopass = false;    // two-pass kernels are set up and may take over small batches
+    int32_t *d_chain_tmp = nullptr; // [2][n_clips][2]: current guesses / step results of multi-clip chains
+    int chain_tmp_cap = 0;
     // two-pass path scratch
     f2 *d_V = nullptr;
     size_t v_bytes = 0;
@@ -183,6 +187,24 @@ int choose_variant(pdog_tracker *t, int forced)
     t->nstrips = (t->n2 + best->tw() - 1) / best->tw();
     t->nthin = 0;
     t->thin_x0 = 0;
+    t->forced_variant = forced >= 0;
+    t->small_twopass = false;
+    {
+        // The two-pass kernels spread one window over dozens of workgroups, so they win whenever the batch
+        // cannot fill the GPU with one wave per strip (single-frame tracking: 36 µs vs 144 µs for one
+        // 257×257 window).  Set them up whenever their LDS tiles fit.
+        const size_t hl = (size_t)HP_ROWS * ((t->n1 + t->L - 1) | 1) * sizeof(f2);
+        const size_t h1l = (size_t)HP_ROWS * ((t->n2 + t->L - 1) | 1) * sizeof(float);
+        if (hl <= kMaxLds - 1024 && h1l <= kMaxLds - 1024) {
+            for (const void *f : {(const void *)dog_hpass_kernel<13, 16, false>, (const void *)dog_hpass_kernel<13, 16, true>}) {
+                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl);
+                if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("hipFuncSetAttribute(hpass): ") + hipGetErrorString(e));
+            }
+            hipError_t e = hipFuncSetAttribute((const void *)dog_h1_kernel<13, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h1l);
+            if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("hipFuncSetAttribute(h1): ") + hipGetErrorString(e));
+            t->small_twopass = true;
+        }
+    }
     if (best->twopass) {
         t->nstrips = (t->n2 + HP_ROWS - 1) / HP_ROWS; // partial slots = 16-column blocks
         const int hl = (int)((size_t)HP_ROWS * ((t->n1 + t->L - 1) | 1) * sizeof(f2));
@@ -257,15 +279,19 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     g.nslots = t->nstrips + t->nthin;
     g.thin_x0 = t->thin_x0;
     g.nthin = t->nthin;
-    if (v.twopass) {
-        g.nslots = t->nstrips;
+    // small batches: fewer than ≈1000 strip-waves cannot fill 256 CUs × 8 waves; the two-pass kernels can
+    const bool small = !v.twopass && !t->forced_variant && t->small_twopass && (long long)n * (t->nstrips + (t->nthin ? 1 : 0)) < 1000;
+    if (v.twopass || small) {
+        const int tp_slots = (t->n2 + HP_ROWS - 1) / HP_ROWS; // partial slots = 16-column blocks
+        g.nstrips = tp_slots;
+        g.nslots = tp_slots;
         g.nthin = 0;
         TwoPassGeo tg;
         tg.g = g;
         tg.TWin = t->n2 + t->L - 1;
         tg.NA = t->n1 + t->L - 1;
         tg.h1blocks_per_win = (tg.NA + HP_ROWS - 1) / HP_ROWS;
-        tg.hblocks_per_win = t->nstrips;
+        tg.hblocks_per_win = tp_slots;
         tg.pitchA = tg.TWin | 1;
         tg.pitchV = tg.NA | 1;
         const size_t per_win = (size_t)t->n2 * tg.NA * sizeof(f2);
@@ -483,6 +509,7 @@ int pdog_destroy(pdog_tracker *t)
     if (t->d_resp) (void)hipFree(t->d_resp);
     if (t->d_V) (void)hipFree(t->d_V);
     if (t->d_dc) (void)hipFree(t->d_dc);
+    if (t->d_chain_tmp) (void)hipFree(t->d_chain_tmp);
     if (t->aux_stream) { (void)hipStreamSynchronize(t->aux_stream); (void)hipStreamDestroy(t->aux_stream); }
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
@@ -629,7 +656,12 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
     HIP_TRY(hipSetDevice(t->device));
     const Variant &v = *t->var;
     const int chain_strips = (t->n2 + ROLL_TW - 1) / ROLL_TW;
-    if (v.roll && v.chain && chain_strips <= 8) {
+    // Enough clips to fill the GPU with one wave per strip → ONE persistent launch (a workgroup per clip walks
+    // its frames).  Fewer clips are latency-bound by that single wave per strip; then each frame is a small
+    // batch that the two-pass kernels spread over many workgroups (21 µs vs 48 µs per frame, one 45×45 window).
+    const bool persistent = v.roll && v.chain && chain_strips <= 8 &&
+                            (t->forced_variant || !t->small_twopass || (long long)n_clips * chain_strips >= 1000);
+    if (persistent) {
         ChainGeo cg;
         LaunchGeo &g = cg.g;
         std::memset(&g, 0, sizeof g);
@@ -650,11 +682,30 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
         HIP_TRY(hipGetLastError());
         return PDOG_OK;
     }
-    if (t->cap_windows < 1) { int rc = ensure_capacity(t, 1); if (rc) return rc; }
-    for (int c = 0; c < n_clips; ++c) {
-        int rc = chain_by_launches(t, d_frames + (int64_t)c * n_frames * frame_stride, frame_stride, row_stride, n_frames,
-                                   d_start_guesses + 2 * c, d_out_ij + 2 * (int64_t)c * n_frames);
+    if (t->cap_windows < n_clips) {
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        int rc = ensure_capacity(t, n_clips);
         if (rc) return rc;
+    }
+    if (n_clips == 1) // stream order is the dependency: frame k's guess is read straight from frame k-1's answer
+        return chain_by_launches(t, d_frames, frame_stride, row_stride, n_frames, d_start_guesses, d_out_ij);
+    if (t->chain_tmp_cap < n_clips) {
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        if (t->d_chain_tmp) (void)hipFree(t->d_chain_tmp);
+        t->d_chain_tmp = nullptr; t->chain_tmp_cap = 0;
+        HIP_TRY(hipMalloc(&t->d_chain_tmp, sizeof(int32_t) * 4 * (size_t)n_clips));
+        t->chain_tmp_cap = n_clips;
+    }
+    int32_t *cur = t->d_chain_tmp, *step = t->d_chain_tmp + 2 * (size_t)n_clips;
+    HIP_TRY(hipMemcpyAsync(cur, d_start_guesses, sizeof(int32_t) * 2 * (size_t)n_clips, hipMemcpyDeviceToDevice, t->stream));
+    for (int k = 0; k < n_frames; ++k) {
+        // step k: window c looks at clip c's frame k = frame (c*n_frames + k): a batch whose frame stride is one clip
+        int rc = launch_detect(t, d_frames + (int64_t)k * frame_stride, frame_stride * n_frames, row_stride, nullptr, cur, n_clips,
+                               step, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(dog_chain_step_kernel, dim3((n_clips + 255) / 256), dim3(256), 0, t->stream, step, cur, d_out_ij,
+                           n_clips, n_frames, k);
+        HIP_TRY(hipGetLastError());
     }
     return PDOG_OK;
 }

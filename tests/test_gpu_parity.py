@@ -290,13 +290,23 @@ def test_persistent_multi_clip_chains(pt, oracle):
                 ot.data[...] = f
                 r.append(ot(r[-1]))
             refs.append(r)
-        bt = pt.BatchTracker(h, w, tw, ws, True, fill)
-        out = bt.detect_chains(torch.from_numpy(np.stack(clips)).cuda(), torch.tensor(starts, dtype=torch.int32).cuda())
-        bt.sync()
-        got = out.cpu().numpy()
-        for c in range(nclips):
-            assert [tuple(int(v) for v in r) for r in got[c]] == refs[c], (ws, c)
-        bt.close()
+        d_clips = torch.from_numpy(np.stack(clips)).cuda()
+        d_starts = torch.tensor(starts, dtype=torch.int32).cuda()
+        # default: few clips run as small per-frame batches; with the kernel pinned (set_variant) the
+        # persistent one-launch chain kernel runs — both must reproduce the oracle's chains
+        for pin in (False, True):
+            bt = pt.BatchTracker(h, w, tw, ws, True, fill)
+            if pin:
+                if bt.info().variant < 100 or bt.info().variant >= 200:
+                    bt.close()
+                    continue      # no roll instance (hence no persistent kernel) for this kernel length
+                bt.set_variant(bt.info().variant)
+            out = bt.detect_chains(d_clips, d_starts)
+            bt.sync()
+            got = out.cpu().numpy()
+            for c in range(nclips):
+                assert [tuple(int(v) for v in r) for r in got[c]] == refs[c], (ws, c, pin)
+            bt.close()
 
 
 def test_extreme_parameters_do_not_break(pt, oracle):
