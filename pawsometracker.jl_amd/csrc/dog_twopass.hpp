@@ -75,11 +75,13 @@ __global__ __launch_bounds__(256) void dog_h1_kernel(const TwoPassGeo tg, const 
         const int a = a0 + r, gi = ti0 + a;
         const bool rowok = (a < tg.NA) && gi >= 0 && gi < g.fh;
         const uint8_t *src = frame + (long long)gi * g.row_stride;
-        for (int c = lane; c < tg.TWin; c += 64) {
+        // the row is staged out to the LDS pitch (zeros past the tile): the sliding windows of the last,
+        // partly masked output group then read in-bounds without any per-read clamp
+        for (int c = lane; c < tg.pitchA; c += 64) {
             const int gj = wj0 + c;
             int v = g.fill;
-            if (rowok && gj >= 0 && gj < g.fw) v = src[gj];
-            A[r * tg.pitchA + c] = (float)(v - dc);
+            if (rowok && c < tg.TWin && gj >= 0 && gj < g.fw) v = src[gj];
+            A[r * tg.pitchA + c] = (c < tg.TWin) ? (float)(v - dc) : 0.f;
         }
     }
     __syncthreads();
@@ -87,9 +89,8 @@ __global__ __launch_bounds__(256) void dog_h1_kernel(const TwoPassGeo tg, const 
     const int r = tid % HP_ROWS, gx = tid / HP_ROWS;
     const int a = a0 + r;
     for (int xb = gx * P; xb < g.n2; xb += XG * P) {
-        const float *in = A + r * tg.pitchA + xb; // inputs in[0 .. P+L-2]; clamp reads of masked outputs
-        const int imax = tg.TWin - 1 - xb;
-        auto ld = [&](int i) { return in[min(max(i, 0), imax)]; };
+        const float *in = A + r * tg.pitchA + xb; // inputs in[0 .. P+L-2] (+ prefetch overrun: zero padding)
+        auto ld = [&](int i) { return in[i]; };
         f2 acc[P];
 #pragma unroll
         for (int o = 0; o < P; ++o) acc[o] = f2{0.f, 0.f};
@@ -165,9 +166,9 @@ __global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, con
         for (int r = wave; r < HP_ROWS; r += NW) {
             f2 *dst = Vs + r * tg.pitchV;
             if (r < nrows) {
-                for (int c = lane; c < tg.NA; c += 64) dst[c] = src[(long long)r * tg.NA + c];
+                for (int c = lane; c < tg.pitchV; c += 64) dst[c] = (c < tg.NA) ? src[(long long)r * tg.NA + c] : f2{0.f, 0.f};
             } else {
-                for (int c = lane; c < tg.NA; c += 64) dst[c] = f2{0.f, 0.f};
+                for (int c = lane; c < tg.pitchV; c += 64) dst[c] = f2{0.f, 0.f};
             }
         }
     }
@@ -182,9 +183,8 @@ __global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, con
         f2 acc[P];
 #pragma unroll
         for (int o = 0; o < P; ++o) acc[o] = f2{0.f, 0.f};
-        // the window may run past the staged row for masked outputs (x ≥ n2): clamp the reads
-        const int amax = tg.NA - 1 - xb;
-        auto ld = [&](int i) { return a[min(i, amax)]; };
+        // rows are staged out to the LDS pitch (zeros past NA): no clamp on the window reads
+        auto ld = [&](int i) { return a[i]; };
         f2 win[P + U - 1];
 #pragma unroll
         for (int j = 0; j < P + U - 1; ++j) win[j] = ld(j);

@@ -152,6 +152,10 @@ struct pdog_tracker {
 
 namespace {
 
+// LDS row pitches of the two-pass kernels: the sliding windows (and their one-block prefetch) of the last,
+// partly masked group of 13 outputs must stay inside the zero-padded row.  nout outputs, l taps.
+int twopass_pitch(int nout, int L) { return (round_up(nout, 16 * 13) + L + 16) | 1; }
+
 int choose_variant(pdog_tracker *t, int forced)
 {
     const Variant *best = nullptr;
@@ -163,7 +167,7 @@ int choose_variant(pdog_tracker *t, int forced)
         if (v.lds(t->L) > kMaxLds) continue;
         if (forced < 0 && t->L >= 80 && !v.twopass) continue; // long kernels: two-pass path (measured 1.7× the ring kernel at l = 293)
         if (v.twopass) {
-            const size_t hl = (size_t)HP_ROWS * ((t->n1 + t->L - 1) | 1) * sizeof(f2);
+            const size_t hl = (size_t)HP_ROWS * twopass_pitch(t->n1, t->L) * sizeof(f2);
             if (hl > kMaxLds - 1024) continue;
             if (forced < 0 && t->L < 80) continue; // the ring/roll kernels win for short kernels
             if (!best || forced >= 0) { best = &v; best_cost = 0.0; }
@@ -193,8 +197,8 @@ int choose_variant(pdog_tracker *t, int forced)
         // The two-pass kernels spread one window over dozens of workgroups, so they win whenever the batch
         // cannot fill the GPU with one wave per strip (single-frame tracking: 36 µs vs 144 µs for one
         // 257×257 window).  Set them up whenever their LDS tiles fit.
-        const size_t hl = (size_t)HP_ROWS * ((t->n1 + t->L - 1) | 1) * sizeof(f2);
-        const size_t h1l = (size_t)HP_ROWS * ((t->n2 + t->L - 1) | 1) * sizeof(float);
+        const size_t hl = (size_t)HP_ROWS * twopass_pitch(t->n1, t->L) * sizeof(f2);
+        const size_t h1l = (size_t)HP_ROWS * twopass_pitch(t->n2, t->L) * sizeof(float);
         if (hl <= kMaxLds - 1024 && h1l <= kMaxLds - 1024) {
             for (const void *f : {(const void *)dog_hpass_kernel<13, 16, false>, (const void *)dog_hpass_kernel<13, 16, true>}) {
                 hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl);
@@ -207,8 +211,8 @@ int choose_variant(pdog_tracker *t, int forced)
     }
     if (best->twopass) {
         t->nstrips = (t->n2 + HP_ROWS - 1) / HP_ROWS; // partial slots = 16-column blocks
-        const int hl = (int)((size_t)HP_ROWS * ((t->n1 + t->L - 1) | 1) * sizeof(f2));
-        const int h1l = (int)((size_t)HP_ROWS * ((t->n2 + t->L - 1) | 1) * sizeof(float));
+        const int hl = (int)((size_t)HP_ROWS * twopass_pitch(t->n1, t->L) * sizeof(f2));
+        const int h1l = (int)((size_t)HP_ROWS * twopass_pitch(t->n2, t->L) * sizeof(float));
         for (const void *f : {(const void *)dog_hpass_kernel<13, 16, false>, (const void *)dog_hpass_kernel<13, 16, true>}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, hl);
             if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("hipFuncSetAttribute(hpass): ") + hipGetErrorString(e));
@@ -292,8 +296,8 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         tg.NA = t->n1 + t->L - 1;
         tg.h1blocks_per_win = (tg.NA + HP_ROWS - 1) / HP_ROWS;
         tg.hblocks_per_win = tp_slots;
-        tg.pitchA = tg.TWin | 1;
-        tg.pitchV = tg.NA | 1;
+        tg.pitchA = twopass_pitch(t->n2, t->L);
+        tg.pitchV = twopass_pitch(t->n1, t->L);
         const size_t per_win = (size_t)t->n2 * tg.NA * sizeof(f2);
         const size_t cap = (size_t)6 << 30;
         const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, cap / per_win));
