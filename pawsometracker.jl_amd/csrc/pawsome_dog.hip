@@ -631,7 +631,7 @@ int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride
     return PDOG_OK;
 }
 
-} // extern "C" (first part)
+} // extern "C"
 
 namespace {
 
@@ -724,5 +724,3 @@ extern "C" int pdog_detect_chain(pdog_tracker *t, const uint8_t *d_frames, int64
     return pdog_detect_chains(t, d_frames, frame_stride, row_stride, n_frames, 1, t->d_small, d_out_ij);
 }
 
-extern "C" {
-} // extern "C"
