@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--noise", type=int, default=3, help="± uniform noise levels on the synthetic frames")
     ap.add_argument("--variant", type=int, default=-1, help="force a kernel specialisation")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--data-rank", type=int, default=-1, help="generate the synthetic data of this rank (checks the per-rank seeds on one GPU)")
     args = ap.parse_args()
 
     import numpy as np
@@ -134,7 +135,8 @@ def main():
     ws = pt.fix_window_size(ws if not isinstance(ws, tuple) else (ws[1], ws[0]))   # (w,h) -> (h,w), :70
     radii = (ws[0] // 2, ws[1] // 2)
     fill = 128
-    frames, guesses_h, centres = make_frames(torch, batch, fh, fw, tw, radii, seed=1000 * rank, noise=args.noise, device=dev)
+    frames, guesses_h, centres = make_frames(torch, batch, fh, fw, tw, radii, seed=1000 * (args.data_rank if args.data_rank >= 0 else rank),
+                                             noise=args.noise, device=dev)
     if args.noise:
         fill = pt.mode(frames[0].cpu().numpy())                 # mode of the first frame, :47
     guesses = torch.from_numpy(guesses_h).to(dev)
