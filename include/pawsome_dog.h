@@ -81,6 +81,12 @@ int pdog_gaussian_taps(double target_width, int which, double *out, int cap);
  * count exceeds the running maximum while scanning column-major). Host pointer. */
 int pdog_mode_u8(const uint8_t *img, int h, int w, int64_t row_stride, int *out_mode);
 
+/* The same for a frame that already lives in device memory (one histogram pass on the GPU, 2 KB read
+ * back; same tie rule: equal counts -> the value whose last occurrence comes first column-major).
+ * Synchronous on hip_stream (NULL = the null stream). */
+int pdog_mode_u8_device(int device, const uint8_t *d_img, int h, int w, int64_t row_stride,
+                        void *hip_stream, int *out_mode);
+
 /* ---- Tracker constructor, src/PawsomeTracker.jl:39-52 ----
  * win_h/win_w: window_size in (h, w) order; fill: the mode of the first frame
  * (pdog_mode_u8), frozen for the tracker's life like :47.  device: HIP ordinal. */

@@ -15,7 +15,7 @@ PDOG_OK, PDOG_E_ARG, PDOG_E_HIP, PDOG_E_NODEV, PDOG_E_RANGE, PDOG_E_ALLOC = rang
 # every symbol include/pawsome_dog.h declares (tests check the library exports them all)
 SYMBOLS = (
     "pdog_abi_version", "pdog_last_error", "pdog_sigma", "pdog_default_window", "pdog_kernel_len",
-    "pdog_gaussian_taps", "pdog_mode_u8", "pdog_create", "pdog_destroy", "pdog_get_info",
+    "pdog_gaussian_taps", "pdog_mode_u8", "pdog_mode_u8_device", "pdog_create", "pdog_destroy", "pdog_get_info",
     "pdog_set_fill", "pdog_set_stream", "pdog_reserve", "pdog_set_variant", "pdog_sync",
     "pdog_detect_batch", "pdog_detect_host", "pdog_detect_chain", "pdog_detect_chains",
 )
@@ -60,6 +60,8 @@ def lib():
     L.pdog_kernel_len.restype = i; L.pdog_kernel_len.argtypes = [d]
     L.pdog_gaussian_taps.restype = i; L.pdog_gaussian_taps.argtypes = [d, i, p, i]
     L.pdog_mode_u8.restype = i; L.pdog_mode_u8.argtypes = [p, i, i, i64, C.POINTER(i)]
+    if hasattr(L, "pdog_mode_u8_device"):
+        L.pdog_mode_u8_device.restype = i; L.pdog_mode_u8_device.argtypes = [i, p, i, i, i64, p, C.POINTER(i)]
     L.pdog_create.restype = i; L.pdog_create.argtypes = [i, i, i, d, i, i, i, i, C.POINTER(p)]
     L.pdog_destroy.restype = i; L.pdog_destroy.argtypes = [p]
     L.pdog_get_info.restype = i; L.pdog_get_info.argtypes = [p, C.POINTER(PdogInfo)]

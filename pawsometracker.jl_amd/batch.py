@@ -108,6 +108,17 @@ class BatchTracker:
             pass
 
 
+def mode_device(frame):
+    """mode(_img) (src/PawsomeTracker.jl:47, StatsBase tie rule) of a uint8 cuda tensor [h, w]."""
+    import torch
+    assert frame.is_cuda and frame.dtype == torch.uint8 and frame.dim() == 2 and frame.stride(1) == 1
+    out = C.c_int()
+    dev = frame.device.index if frame.device.index is not None else torch.cuda.current_device()
+    _lib.check(_lib.lib().pdog_mode_u8_device(dev, C.c_void_p(frame.data_ptr()), frame.shape[0], frame.shape[1], frame.stride(0),
+                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), C.byref(out)))
+    return out.value
+
+
 def shard_range(n, rank, world_size):
     """Contiguous window range [lo, hi) owned by `rank`: sizes differ by at most 1."""
     base, rem = divmod(int(n), int(world_size))

@@ -385,4 +385,30 @@ __global__ void dog_finalize_kernel(const float *__restrict__ part_val, const in
     out_ij[2 * b + 1] = j;
 }
 
+// mode(_img), src/PawsomeTracker.jl:47, for a frame that already lives on the device.  StatsBase.mode keeps
+// the value whose count FIRST exceeds the running maximum while scanning the h×w view column-major.  Every
+// value that ends with the maximum count M reaches M at its LAST occurrence, so the winner is: largest count,
+// ties → the value whose last occurrence comes earliest in column-major order (index j·h + i).  One pass:
+// per-workgroup LDS histogram + last-occurrence table, flushed with atomics; 2 KB go back to the host.
+__global__ __launch_bounds__(256) void dog_mode_kernel(const uint8_t *__restrict__ img, int h, int w, long long row_stride,
+                                                       unsigned *__restrict__ hist, unsigned *__restrict__ last)
+{
+    __shared__ unsigned shist[256], slast[256];
+    shist[threadIdx.x] = 0;
+    slast[threadIdx.x] = 0;
+    __syncthreads();
+    const long long total = (long long)h * w;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(p / w), j = (int)(p - (long long)i * w);
+        const unsigned v = img[(long long)i * row_stride + j];
+        atomicAdd(&shist[v], 1u);
+        atomicMax(&slast[v], (unsigned)((long long)j * h + i) + 1u); // +1: 0 means "never seen"
+    }
+    __syncthreads();
+    if (shist[threadIdx.x]) {
+        atomicAdd(&hist[threadIdx.x], shist[threadIdx.x]);
+        atomicMax(&last[threadIdx.x], slast[threadIdx.x]);
+    }
+}
+
 } // namespace pdog

@@ -412,6 +412,32 @@ int pdog_mode_u8(const uint8_t *img, int h, int w, int64_t row_stride, int *out_
     return PDOG_OK;
 }
 
+int pdog_mode_u8_device(int device, const uint8_t *d_img, int h, int w, int64_t row_stride, void *hip_stream, int *out_mode)
+{
+    if (!d_img || !out_mode || h <= 0 || w <= 0 || row_stride < w || (long long)h * w >= 0xffffffffLL)
+        return fail(PDOG_E_ARG, "pdog_mode_u8_device: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    unsigned *d_tab = nullptr;
+    HIP_TRY(hipMalloc(&d_tab, sizeof(unsigned) * 512));
+    unsigned tab[512];
+    hipError_t e = hipMemsetAsync(d_tab, 0, sizeof(unsigned) * 512, stream);
+    if (e == hipSuccess) {
+        const int blocks = (int)std::min<long long>(1024, ((long long)h * w + 255) / 256);
+        hipLaunchKernelGGL(dog_mode_kernel, dim3(blocks), dim3(256), 0, stream, d_img, h, w, (long long)row_stride, d_tab, d_tab + 256);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(tab, d_tab, sizeof tab, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_tab);
+    if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("pdog_mode_u8_device: ") + hipGetErrorString(e));
+    int best = 0;
+    for (int v = 1; v < 256; ++v)
+        if (tab[v] > tab[best] || (tab[v] == tab[best] && tab[256 + v] < tab[256 + best])) best = v;
+    *out_mode = best;
+    return PDOG_OK;
+}
+
 int pdog_create(int device, int frame_h, int frame_w, double target_width, int win_h, int win_w,
                 int darker_target, int fill, pdog_tracker **out)
 {

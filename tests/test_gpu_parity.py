@@ -335,3 +335,20 @@ def test_extreme_parameters_do_not_break(pt, oracle):
         exp = (max(1, guess[0] - ws[0] // 2), max(1, guess[1] - ws[1] // 2))
         assert t(guess) == exp, (tw, ws, t.info().variant)
         t.close()
+
+
+def test_device_mode_matches_statsbase_rule(pt, oracle):
+    """pdog_mode_u8_device against the oracle's literal StatsBase scan, including engineered count ties."""
+    import torch
+    rng = np.random.default_rng(2)
+    imgs = [rng.integers(0, 256, (37, 53), dtype=np.uint8), rng.integers(0, 3, (64, 64), dtype=np.uint8),
+            np.full((20, 30), 7, np.uint8), rng.integers(100, 104, (1080, 1920), dtype=np.uint8)]
+    tie = np.zeros((4, 6), np.uint8)           # 12 x value 0 ... make exact ties between 1, 2 and 3
+    tie[:, 0] = 1; tie[:, 1] = 2; tie[:, 2] = 3; tie[:, 3] = [2, 1, 3, 9]; tie[:, 4] = [3, 2, 1, 9]; tie[:, 5] = 9
+    imgs.append(tie)
+    for _ in range(20):                        # small alphabets force ties
+        imgs.append(rng.integers(0, 4, (int(rng.integers(2, 9)), int(rng.integers(2, 9))), dtype=np.uint8))
+    for img in imgs:
+        assert pt.mode_device(torch.from_numpy(img).cuda()) == oracle.mode_u8(img), img.shape
+    view = torch.from_numpy(rng.integers(0, 5, (50, 80), dtype=np.uint8)).cuda()[:, 10:47]   # strided rows
+    assert pt.mode_device(view) == oracle.mode_u8(view.cpu().numpy())
