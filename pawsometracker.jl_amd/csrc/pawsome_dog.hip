@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -46,6 +48,24 @@ void gaussian_1d(double s, int l, double *g)
     double sum = 0.0;
     for (int i = 0; i < l; ++i) sum += g[i];
     for (int i = 0; i < l; ++i) g[i] /= sum;
+}
+
+// MaxDynamicSharedMemorySize is a per-function (per-device) attribute shared by every tracker in the
+// process: only ever raise it, so that a tracker with a small window cannot shrink the limit under a
+// live tracker with a large one.
+int raise_lds_limit(const void *fn, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> limit;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(PDOG_E_HIP, "hipGetDevice failed");
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &cur = limit[{dev, fn}];
+    if (bytes <= cur) return PDOG_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
+    cur = bytes;
+    return PDOG_OK;
 }
 
 // ---- compiled kernel specialisations ----
@@ -201,11 +221,9 @@ int choose_variant(pdog_tracker *t, int forced)
         const size_t h1l = (size_t)HP_ROWS * twopass_pitch(t->n2, t->L) * sizeof(float);
         if (hl <= kMaxLds - 1024 && h1l <= kMaxLds - 1024) {
             for (const void *f : {(const void *)dog_hpass_kernel<13, 16, false>, (const void *)dog_hpass_kernel<13, 16, true>}) {
-                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl);
-                if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("hipFuncSetAttribute(hpass): ") + hipGetErrorString(e));
+                if (int rc = raise_lds_limit(f, hl)) return rc;
             }
-            hipError_t e = hipFuncSetAttribute((const void *)dog_h1_kernel<13, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h1l);
-            if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("hipFuncSetAttribute(h1): ") + hipGetErrorString(e));
+            if (int rc = raise_lds_limit((const void *)dog_h1_kernel<13, 8>, h1l)) return rc;
             t->small_twopass = true;
         }
     }
@@ -214,11 +232,9 @@ int choose_variant(pdog_tracker *t, int forced)
         const int hl = (int)((size_t)HP_ROWS * twopass_pitch(t->n1, t->L) * sizeof(f2));
         const int h1l = (int)((size_t)HP_ROWS * twopass_pitch(t->n2, t->L) * sizeof(float));
         for (const void *f : {(const void *)dog_hpass_kernel<13, 16, false>, (const void *)dog_hpass_kernel<13, 16, true>}) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, hl);
-            if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("hipFuncSetAttribute(hpass): ") + hipGetErrorString(e));
+            if (int rc = raise_lds_limit(f, (size_t)hl)) return rc;
         }
-        hipError_t e = hipFuncSetAttribute((const void *)dog_h1_kernel<13, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, h1l);
-        if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("hipFuncSetAttribute(h1): ") + hipGetErrorString(e));
+        if (int rc = raise_lds_limit((const void *)dog_h1_kernel<13, 8>, (size_t)h1l)) return rc;
         return PDOG_OK;
     }
     if (best->roll && best->thin && t->n2 > best->tw()) {
@@ -227,8 +243,7 @@ int choose_variant(pdog_tracker *t, int forced)
         const size_t thin_lds = sizeof(f2) * (size_t)(t->n1 + t->L - 1);
         if (r > 0 && r <= kThinMax && thin_lds <= kMaxLds - 1024) {
             for (kernel_fn f : {best->thin, best->thin_resp}) {
-                hipError_t e = hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)thin_lds);
-                if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("hipFuncSetAttribute(thin): ") + hipGetErrorString(e));
+                if (int rc = raise_lds_limit((const void *)f, thin_lds)) return rc;
             }
             t->nthin = r;
             t->thin_x0 = t->n2 - r;
@@ -236,8 +251,7 @@ int choose_variant(pdog_tracker *t, int forced)
         }
     }
     for (kernel_fn f : {best->fn, best->fn_resp}) {
-        hipError_t e = hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)best->lds(t->L));
-        if (e != hipSuccess) return fail(PDOG_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        if (int rc = raise_lds_limit((const void *)f, best->lds(t->L))) return rc;
     }
     return PDOG_OK;
 }
@@ -354,7 +368,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
 #ifdef PDOG_ABLATIONS
     if (const char *e = std::getenv("PDOG_LDS_PAD")) { // occupancy experiments: extra LDS per workgroup
         lds_bytes += (size_t)std::atoi(e);
-        (void)hipFuncSetAttribute((const void *)(d_out_resp ? v.fn_resp : v.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)raise_lds_limit((const void *)(d_out_resp ? v.fn_resp : v.fn), lds_bytes);
     }
 #endif
     hipLaunchKernelGGL(d_out_resp ? v.fn_resp : v.fn, dim3(grid), dim3(v.NT), lds_bytes, t->stream, g,
@@ -706,7 +720,7 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
         cg.out_ij = d_out_ij;
         cg.n_frames = n_frames;
         const size_t lds = (size_t)chain_strips * roll_lds_bytes(v.LT);
-        HIP_TRY(hipFuncSetAttribute((const void *)v.chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (int rc = raise_lds_limit((const void *)v.chain, lds)) return rc;
         hipLaunchKernelGGL(v.chain, dim3(n_clips), dim3(64 * chain_strips), lds, t->stream, cg,
                            (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_roll);
         HIP_TRY(hipGetLastError());

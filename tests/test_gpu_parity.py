@@ -352,3 +352,22 @@ def test_device_mode_matches_statsbase_rule(pt, oracle):
         assert pt.mode_device(torch.from_numpy(img).cuda()) == oracle.mode_u8(img), img.shape
     view = torch.from_numpy(rng.integers(0, 5, (50, 80), dtype=np.uint8)).cuda()[:, 10:47]   # strided rows
     assert pt.mode_device(view) == oracle.mode_u8(view.cpu().numpy())
+
+
+def test_trackers_with_different_geometry_coexist(pt, oracle):
+    """Several live trackers share the compiled kernels (and their per-function dynamic-LDS limit): a small
+    tracker created later must not break a large one created earlier (multi-video use, README.md:214 of the
+    reference: concurrent `track` calls own separate Trackers)."""
+    from oracle import synth
+    rng = np.random.default_rng(9)
+    big = np.clip(synth.disc_frame(400, 500, (200, 250), 120, True).astype(np.int16) + rng.integers(-3, 4, (400, 500)), 0, 255).astype(np.uint8)
+    small = np.clip(synth.disc_frame(120, 160, (60, 80), 25, True).astype(np.int16) + rng.integers(-3, 4, (120, 160)), 0, 255).astype(np.uint8)
+    tb = pt.Tracker(big, 120, (151, 151), True)       # two-pass kernels, large LDS rows
+    first = tb((195, 258))
+    ts = pt.Tracker(small, 25, (45, 45), True)         # same kernels at launch time (small batch), small LDS rows
+    assert ts((55, 85)) == (60, 80)
+    tw = pt.Tracker(small, 25, (257, 257), True)       # roll kernel family set up too
+    assert tw((55, 85)) == (60, 80)
+    assert tb((195, 258)) == first == (200, 250)
+    for t in (tb, ts, tw):
+        t.close()
