@@ -371,3 +371,40 @@ def test_trackers_with_different_geometry_coexist(pt, oracle):
     assert tb((195, 258)) == first == (200, 250)
     for t in (tb, ts, tw):
         t.close()
+
+
+def test_textured_frames_batch_vs_oracle(pt, oracle):
+    """Frames that look like video rather than like the reference's flat test clips: smooth large-scale
+    texture + sensor noise + a dark blob, so the window level sits far from the frame's mode (exercises the
+    per-window DC level) and the peak competes with texture.  200 windows, positions exact."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(77)
+    h, w, tw, ws, n = 360, 480, 25, (45, 45), 200
+    base = gaussian_filter(rng.standard_normal((h, w)), 25)
+    base = (base - base.min()) / (base.max() - base.min())            # 0..1 smooth texture
+    frames = np.empty((8, h, w), np.uint8)
+    centres = []
+    for k in range(8):
+        img = 60 + 150 * base + rng.normal(0, 4, (h, w))
+        c = (int(rng.integers(30, h - 30)), int(rng.integers(30, w - 30)))
+        yy, xx = np.ogrid[:h, :w]
+        img[(yy - c[0]) ** 2 + (xx - c[1]) ** 2 <= 144] -= 70          # dark blob, radius 12
+        frames[k] = np.clip(img, 0, 255).astype(np.uint8)
+        centres.append(c)
+    fi = rng.integers(0, 8, n).astype(np.int32)
+    guesses = np.stack([rng.integers(1, h + 1, n), rng.integers(1, w + 1, n)], 1).astype(np.int32)
+    near = rng.random(n) < 0.5                                          # half of the windows contain the blob
+    for b in np.flatnonzero(near):
+        guesses[b] = np.array(centres[fi[b]]) + rng.integers(-12, 13, 2)
+    fill = oracle.mode_u8(frames[0])
+    K = oracle.dog_kernel(oracle.sigma(tw), True)
+    ref = np.array([oracle.detect(frames[fi[b]], fill, K, (22, 22), guesses[b]) for b in range(n)], np.int32)
+    got, resp = _batch(pt, frames, guesses, tw, ws, True, fill, frame_index=fi, want_resp=True)
+    assert np.array_equal(got, ref), np.flatnonzero((got != ref).any(1))
+    for b in (0, 50, 199):
+        _, r = oracle.detect(frames[fi[b]], fill, K, (22, 22), guesses[b], want_resp=True)
+        _check_resp(resp[b].T, r, f"textured{b}")
+    # large batch path (roll kernel) on the same data: 4 x the windows so that the batch is not "small"
+    big = np.tile(guesses, (6, 1)); bfi = np.tile(fi, 6)
+    got_big = _batch(pt, frames, big, tw, ws, True, fill, frame_index=bfi)
+    assert np.array_equal(got_big, np.tile(ref, (6, 1)))
