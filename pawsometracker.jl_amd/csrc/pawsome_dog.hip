@@ -313,7 +313,8 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         tg.pitchA = twopass_pitch(t->n2, t->L);
         tg.pitchV = twopass_pitch(t->n1, t->L);
         const size_t per_win = (size_t)t->n2 * tg.NA * sizeof(f2);
-        const size_t cap = (size_t)6 << 30;
+        size_t cap = (size_t)6 << 30; // HBM scratch for the transposed intermediate; larger batches go in chunks
+        if (const char *e = std::getenv("PDOG_SCRATCH_MB")) cap = (size_t)std::max(1, std::atoi(e)) << 20;
         const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, cap / per_win));
         if (t->v_bytes < per_win * chunk || t->dc_cap < n) {
             HIP_TRY(hipStreamSynchronize(t->stream));

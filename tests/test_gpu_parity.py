@@ -354,6 +354,21 @@ def test_device_mode_matches_statsbase_rule(pt, oracle):
     assert pt.mode_device(view) == oracle.mode_u8(view.cpu().numpy())
 
 
+def test_two_pass_scratch_chunking(pt, oracle, monkeypatch):
+    """The two-pass path keeps its intermediate in an HBM scratch buffer and walks large batches in chunks;
+    force a tiny scratch so that a 40-window batch takes many chunks."""
+    from oracle import synth
+    tw, ws, radii = 40, (61, 61), (30, 30)
+    frames, guesses, _ = synth.make_batch(40, 160, 200, tw, radii, True, seed=3, noise=3)
+    fill = oracle.mode_u8(frames[0])
+    K = oracle.dog_kernel(oracle.sigma(tw), True)
+    ref = oracle.detect_batch(frames, fill, K, radii, guesses)
+    monkeypatch.setenv("PDOG_SCRATCH_MB", "1")          # 61 x 161 x 8 B = 79 KB per window -> 13 windows per chunk
+    assert np.array_equal(_batch(pt, frames, guesses, tw, ws, True, fill), ref)
+    monkeypatch.delenv("PDOG_SCRATCH_MB")
+    assert np.array_equal(_batch(pt, frames, guesses, tw, ws, True, fill), ref)
+
+
 def test_trackers_with_different_geometry_coexist(pt, oracle):
     """Several live trackers share the compiled kernels (and their per-function dynamic-LDS limit): a small
     tracker created later must not break a large one created earlier (multi-video use, README.md:214 of the
