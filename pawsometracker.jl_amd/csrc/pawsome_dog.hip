@@ -167,6 +167,7 @@ struct pdog_tracker {
     // host-path staging (pdog_detect_host / chain seed)
     uint8_t *d_frame = nullptr;
     int32_t *d_small = nullptr; // [0..1] guess, [2..3] result
+    int32_t *h_pinned = nullptr; // pinned mirror of d_small: the host path's 8-byte copies skip the pageable staging
     float *d_resp = nullptr;
 };
 
@@ -532,6 +533,7 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
         CREATE_TRY(hipMemcpy(t->d_taps_roll, tab.data(), sizeof(f2) * tab.size(), hipMemcpyHostToDevice));
     }
     CREATE_TRY(hipMalloc(&t->d_small, sizeof(int32_t) * 4));
+    CREATE_TRY(hipHostMalloc(&t->h_pinned, sizeof(int32_t) * 4, hipHostMallocDefault));
 #undef CREATE_TRY
     rc = ensure_capacity(t, 1);
     if (rc) { pdog_destroy(t); return rc; }
@@ -551,6 +553,7 @@ int pdog_destroy(pdog_tracker *t)
     if (t->d_part_idx) (void)hipFree(t->d_part_idx);
     if (t->d_frame) (void)hipFree(t->d_frame);
     if (t->d_small) (void)hipFree(t->d_small);
+    if (t->h_pinned) (void)hipHostFree(t->h_pinned);
     if (t->d_resp) (void)hipFree(t->d_resp);
     if (t->d_V) (void)hipFree(t->d_V);
     if (t->d_dc) (void)hipFree(t->d_dc);
@@ -662,13 +665,17 @@ int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride
             HIP_TRY(hipMemcpy2DAsync(t->d_frame + (size_t)r_lo * t->fw + c_lo, t->fw, h_frame + (size_t)r_lo * row_stride + c_lo,
                                      row_stride, (size_t)(c_hi - c_lo), (size_t)(r_hi - r_lo), hipMemcpyHostToDevice, t->stream));
     }
-    HIP_TRY(hipMemcpyAsync(t->d_small, guess, sizeof(int32_t) * 2, hipMemcpyHostToDevice, t->stream));
+    t->h_pinned[0] = guess[0];
+    t->h_pinned[1] = guess[1];
+    HIP_TRY(hipMemcpyAsync(t->d_small, t->h_pinned, sizeof(int32_t) * 2, hipMemcpyHostToDevice, t->stream));
     int rc = launch_detect(t, t->d_frame, (int64_t)t->fh * t->fw, t->fw, nullptr, t->d_small, 1, t->d_small + 2,
                            h_resp ? t->d_resp : nullptr);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out_ij, t->d_small + 2, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->h_pinned + 2, t->d_small + 2, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, t->stream));
     if (h_resp) HIP_TRY(hipMemcpyAsync(h_resp, t->d_resp, sizeof(float) * (size_t)t->n1 * t->n2, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
+    out_ij[0] = t->h_pinned[2];
+    out_ij[1] = t->h_pinned[3];
     return PDOG_OK;
 }
 
