@@ -144,11 +144,11 @@ __global__ __launch_bounds__(256) void dog_h1_kernel(const TwoPassGeo tg, const 
 }
 
 // ---- column pass + peak (on RT) ----
-template <int P, int U, bool RESP>
+template <int P, int U, bool RESP, int HR = HP_ROWS>
 __global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, const f2 *__restrict__ taps_col)
 {
     const LaunchGeo &g = tg.g;
-    constexpr int NT = 256, NW = NT / 64, XG = NT / HP_ROWS;
+    constexpr int NT = 256, NW = NT / 64, XG = NT / HR;
     const int L = g.L;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f2 *Vs = reinterpret_cast<f2 *>(smem);
@@ -158,12 +158,12 @@ __global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, con
     const int b_local = blockIdx.x / tg.hblocks_per_win;
     const int rb = blockIdx.x - b_local * tg.hblocks_per_win;
     const int b = tg.win0 + b_local;
-    const int r0 = rb * HP_ROWS;                 // first window column x of this block
-    const int nrows = min(HP_ROWS, g.n2 - r0);
+    const int r0 = rb * HR;                 // first window column x of this block
+    const int nrows = min(HR, g.n2 - r0);
     // stage: nrows × NA f2, coalesced
     {
         const f2 *src = tg.RT + ((long long)b_local * g.n2 + r0) * tg.NA;
-        for (int r = wave; r < HP_ROWS; r += NW) {
+        for (int r = wave; r < HR; r += NW) {
             f2 *dst = Vs + r * tg.pitchV;
             if (r < nrows) {
                 for (int c = lane; c < tg.pitchV; c += 64) dst[c] = (c < tg.NA) ? src[(long long)r * tg.NA + c] : f2{0.f, 0.f};
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, con
     }
     __syncthreads();
     const tap_ptr taps = as_taps(taps_col);
-    const int r = tid % HP_ROWS, gx = tid / HP_ROWS;
+    const int r = tid % HR, gx = tid / HR;
     float best = -__builtin_huge_valf();
     int best_idx = 0x7fffffff;
     // a workgroup covers XG·P columns per round; wide windows take several rounds

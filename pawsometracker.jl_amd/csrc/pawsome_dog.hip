@@ -147,6 +147,7 @@ struct pdog_tracker {
     int nthin = 0, thin_x0 = 0; // window columns handled by the thin-remainder kernel
     bool forced_variant = false;   // pdog_set_variant pinned the kernel: no batch-size switching
     bool small_twopass = false;    // two-pass kernels are set up and may take over small batches
+    int hp_rows = HP_ROWS;         // RT rows (window columns) per column-pass workgroup: 16 (P = 13) or 8 (P = 7)
     int32_t *d_chain_tmp = nullptr; // [2][n_clips][2]: current guesses / step results of multi-clip chains
     int chain_tmp_cap = 0;
     // two-pass path scratch
@@ -175,7 +176,7 @@ namespace {
 
 // LDS row pitches of the two-pass kernels: the sliding windows (and their one-block prefetch) of the last,
 // partly masked group of 13 outputs must stay inside the zero-padded row.  nout outputs, l taps.
-int twopass_pitch(int nout, int L) { return (round_up(nout, 16 * 13) + L + 16) | 1; }
+int twopass_pitch(int nout, int L, int rows = HP_ROWS) { return (round_up(nout, rows == 8 ? 32 * 7 : 16 * 13) + L + 16) | 1; }
 
 int choose_variant(pdog_tracker *t, int forced)
 {
@@ -224,6 +225,10 @@ int choose_variant(pdog_tracker *t, int forced)
             for (const void *f : {(const void *)dog_hpass_kernel<13, 16, false>, (const void *)dog_hpass_kernel<13, 16, true>}) {
                 if (int rc = raise_lds_limit(f, hl)) return rc;
             }
+            const size_t hl8 = (size_t)8 * twopass_pitch(t->n1, t->L, 8) * sizeof(f2);
+            for (const void *f : {(const void *)dog_hpass_kernel<7, 16, false, 8>, (const void *)dog_hpass_kernel<7, 16, true, 8>}) {
+                if (int rc = raise_lds_limit(f, hl8)) return rc;
+            }
             if (int rc = raise_lds_limit((const void *)dog_h1_kernel<13, 8>, h1l)) return rc;
             t->small_twopass = true;
         }
@@ -234,6 +239,9 @@ int choose_variant(pdog_tracker *t, int forced)
         const int h1l = (int)((size_t)HP_ROWS * twopass_pitch(t->n2, t->L) * sizeof(float));
         for (const void *f : {(const void *)dog_hpass_kernel<13, 16, false>, (const void *)dog_hpass_kernel<13, 16, true>}) {
             if (int rc = raise_lds_limit(f, (size_t)hl)) return rc;
+        }
+        for (const void *f : {(const void *)dog_hpass_kernel<7, 16, false, 8>, (const void *)dog_hpass_kernel<7, 16, true, 8>}) {
+            if (int rc = raise_lds_limit(f, (size_t)8 * twopass_pitch(t->n1, t->L, 8) * sizeof(f2))) return rc;
         }
         if (int rc = raise_lds_limit((const void *)dog_h1_kernel<13, 8>, (size_t)h1l)) return rc;
         return PDOG_OK;
@@ -264,7 +272,7 @@ int ensure_capacity(pdog_tracker *t, int n)
     int max_strips = 1;
     for (int i = 0; i < kNumVariants; ++i)
         max_strips = std::max(max_strips, (t->n2 + kVariants[i].tw() - 1) / kVariants[i].tw() + kThinMax);
-    max_strips = std::max(max_strips, (t->n2 + HP_ROWS - 1) / HP_ROWS);
+    max_strips = std::max(max_strips, (t->n2 + 7) / 8);
     if (t->d_part_val) (void)hipFree(t->d_part_val);
     if (t->d_part_idx) (void)hipFree(t->d_part_idx);
     t->d_part_val = nullptr;
@@ -301,7 +309,8 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     // small batches: fewer than ≈1000 strip-waves cannot fill 256 CUs × 8 waves; the two-pass kernels can
     const bool small = !v.twopass && !t->forced_variant && t->small_twopass && (long long)n * (t->nstrips + (t->nthin ? 1 : 0)) < 1000;
     if (v.twopass || small) {
-        const int tp_slots = (t->n2 + HP_ROWS - 1) / HP_ROWS; // partial slots = 16-column blocks
+        const int hr = std::getenv("PDOG_HPASS16") ? HP_ROWS : 8; // 8 RT rows per workgroup (32 KB LDS → 4 workgroups per CU): +3 % on cfg5 vs 16; env = tuning switch
+        const int tp_slots = (t->n2 + hr - 1) / hr; // partial slots = hr-column blocks
         g.nstrips = tp_slots;
         g.nslots = tp_slots;
         g.nthin = 0;
@@ -312,7 +321,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         tg.h1blocks_per_win = (tg.NA + HP_ROWS - 1) / HP_ROWS;
         tg.hblocks_per_win = tp_slots;
         tg.pitchA = twopass_pitch(t->n2, t->L);
-        tg.pitchV = twopass_pitch(t->n1, t->L);
+        tg.pitchV = twopass_pitch(t->n1, t->L, hr);
         const size_t per_win = (size_t)t->n2 * tg.NA * sizeof(f2);
         size_t cap = (size_t)6 << 30; // HBM scratch for the transposed intermediate; larger batches go in chunks
         if (const char *e = std::getenv("PDOG_SCRATCH_MB")) cap = (size_t)std::max(1, std::atoi(e)) << 20;
@@ -337,13 +346,18 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         hipLaunchKernelGGL(dog_dc_kernel, dim3(n), dim3(64), 0, t->stream, g, t->d_dc);
         HIP_TRY(hipGetLastError());
         const size_t l1 = (size_t)HP_ROWS * tg.pitchA * sizeof(float);
-        const size_t l2 = (size_t)HP_ROWS * tg.pitchV * sizeof(f2);
+        const size_t l2 = (size_t)hr * tg.pitchV * sizeof(f2);
         for (int w0 = 0; w0 < n; w0 += chunk) {
             const int nw = std::min(chunk, n - w0);
             tg.win0 = w0;
             hipLaunchKernelGGL((dog_h1_kernel<13, 8>), dim3(nw * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
             HIP_TRY(hipGetLastError());
-            if (d_out_resp)
+            if (hr == 8) {
+                if (d_out_resp)
+                    hipLaunchKernelGGL((dog_hpass_kernel<7, 16, true, 8>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
+                else
+                    hipLaunchKernelGGL((dog_hpass_kernel<7, 16, false, 8>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
+            } else if (d_out_resp)
                 hipLaunchKernelGGL((dog_hpass_kernel<13, 16, true>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             else
                 hipLaunchKernelGGL((dog_hpass_kernel<13, 16, false>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
