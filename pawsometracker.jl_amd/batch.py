@@ -126,10 +126,26 @@ def shard_range(n, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_positions(local_ij, n_total, group=None, dst=0):
+class _PendingGather:
+    """Handle of an asynchronous gather_positions: wait() returns what the blocking call returns."""
+
+    def __init__(self, work, bufs, sizes, is_dst):
+        self._work, self._bufs, self._sizes, self._is_dst = work, bufs, sizes, is_dst
+
+    def wait(self):
+        import torch
+        self._work.wait()
+        if not self._is_dst:
+            return None
+        return torch.cat([self._bufs[r][: hi - lo] for r, (lo, hi) in enumerate(self._sizes)], 0)
+
+
+def gather_positions(local_ij, n_total, group=None, dst=0, async_op=False):
     """Gather the per-rank int32 [n_local, 2] results to rank `dst` in shard order.
     The only collective on the path: 8 B per window (RCCL gather over xGMI with the
-    nccl backend; gloo on CPU for tests).  Returns the [n_total, 2] tensor on dst, None elsewhere."""
+    nccl backend; gloo on CPU for tests).  Returns the [n_total, 2] tensor on dst, None elsewhere.
+    With async_op=True the collective is only enqueued (it runs beside the next batch's kernels) and a
+    handle is returned whose wait() gives that result."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -139,7 +155,6 @@ def gather_positions(local_ij, n_total, group=None, dst=0):
     pad = torch.zeros((max_n, 2), dtype=torch.int32, device=local_ij.device)
     pad[: local_ij.shape[0]] = local_ij
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dst, group=group)
-    if rank != dst:
-        return None
-    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)
+    work = dist.gather(pad, bufs, dst=dst, group=group, async_op=True)
+    pending = _PendingGather(work, bufs, sizes, rank == dst)
+    return pending if async_op else pending.wait()

@@ -20,10 +20,15 @@ def _worker(rank, world, port, n_total, q):
     # stand-in for the rank's detect() output: row = global window id, col = rank
     local = torch.stack([torch.arange(lo, hi, dtype=torch.int32), torch.full((hi - lo,), rank, dtype=torch.int32)], 1)
     out = pt.gather_positions(local, n_total)
+    # the asynchronous form (bench.py overlaps it with the next batch): several in flight, same answers
+    handles = [pt.gather_positions(local + k, n_total, async_op=True) for k in range(3)]
+    outs = [h.wait() for h in handles]
     if rank == 0:
+        for k in range(3):
+            assert torch.equal(outs[k], out + k)
         q.put(out.tolist())
     else:
-        assert out is None
+        assert out is None and all(o is None for o in outs)
     dist.barrier()
     dist.destroy_process_group()
 
