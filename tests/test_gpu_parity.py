@@ -423,3 +423,35 @@ def test_textured_frames_batch_vs_oracle(pt, oracle):
     big = np.tile(guesses, (6, 1)); bfi = np.tile(fi, 6)
     got_big = _batch(pt, frames, big, tw, ws, True, fill, frame_index=bfi)
     assert np.array_equal(got_big, np.tile(ref, (6, 1)))
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg4", "cfg5"])
+def test_full_size_properties_other_configs(pt, oracle, cfg):
+    """The remaining BASELINE.json geometries at full frame/window size and a reduced batch: known answers
+    that need no oracle (SURVEY §8c i–iv), for a batch large enough to take the batch kernels and for a
+    single window (the small-batch kernels)."""
+    from oracle import synth
+    fh, fw, tw, ws = {"cfg2": (1080, 1920, 25, (270, 480)), "cfg4": (2160, 3840, 25, (512, 512)),
+                      "cfg5": (1080, 1920, 120, (205, 205))}[cfg]
+    radii = (ws[0] // 2, ws[1] // 2)
+    n = 6
+    frames, guesses, centres = synth.make_batch(n, fh, fw, tw, radii, True, seed=21, noise=0)
+    rad = tw // 2 + 1
+    inside = ((centres[:, 0] > rad) & (centres[:, 0] <= fh - rad) & (centres[:, 1] > rad) & (centres[:, 1] <= fw - rad)
+              & (np.abs(centres - guesses) <= np.array(radii) - rad).all(1))
+    assert inside.any()
+    # replicate the batch so that it is not a "small" one (≥ 1000 strip-waves) and compare with the small path
+    rep = 1 + 1000 // max(1, (2 * radii[1] + 1) // 64)
+    fi = np.tile(np.arange(n, dtype=np.int32), rep)
+    got_big = _batch(pt, frames, np.tile(guesses, (rep, 1)), tw, ws, True, 128, frame_index=fi)
+    got_small = _batch(pt, frames, guesses, tw, ws, True, 128)
+    assert np.array_equal(got_big[:n], got_small) and np.array_equal(got_big, np.tile(got_small, (rep, 1)))
+    assert np.array_equal(got_small[inside], centres[inside])                         # (i) disc centre, exactly
+    shifted = _batch(pt, (frames.astype(np.int16) + 40).astype(np.uint8), guesses, tw, ws, True, 168)
+    assert np.array_equal(shifted, got_small)                                         # (iii) + constant
+    bright = _batch(pt, 255 - frames, guesses, tw, ws, False, 127)
+    assert np.array_equal(bright, got_small)                                          # (iv) complement
+    flat = np.full((1, fh, fw), 128, np.uint8)
+    g = np.array([[fh // 2, fw // 2]], np.int32)
+    exp = np.array([[max(1, fh // 2 - radii[0]), max(1, fw // 2 - radii[1])]], np.int32)
+    assert np.array_equal(_batch(pt, flat, g, tw, ws, True, 128), exp)                # (ii) flat window
