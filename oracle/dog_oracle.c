@@ -257,6 +257,33 @@ void pdo_detect_batch_dense(const uint8_t *frames, int64_t frame_stride, int n, 
     }
 }
 
+/* The same n applications with the threads split ACROSS windows (one window per thread, each window
+ * single-threaded): not how one reference `Tracker` call threads (CPUThreads splits the output range of a
+ * single call, as pdo_detect_dense does), but how a host with many clips would use its cores
+ * (README.md:214: concurrent `track` calls are supported) — the stronger CPU baseline for batches.
+ * separable != 0 runs the separable Float64 statement instead of the dense one. */
+void pdo_detect_batch_par(const uint8_t *frames, int64_t frame_stride, int n, int h, int w,
+                          int64_t stride, int fill, const double *K, double sigma, int darker, int l,
+                          int r1, int r2, const int32_t *guesses, int32_t *out_ij, int separable, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+    for (int b = 0; b < n; ++b) {
+        int oi, oj;
+        const uint8_t *f = frames + (int64_t)b * frame_stride;
+        if (separable)
+            pdo_detect_separable(f, h, w, stride, fill, sigma, darker, l, r1, r2,
+                                 guesses[2 * b], guesses[2 * b + 1], &oi, &oj, NULL, 1);
+        else
+            pdo_detect_dense(f, h, w, stride, fill, K, l, r1, r2,
+                             guesses[2 * b], guesses[2 * b + 1], &oi, &oj, NULL, 1);
+        out_ij[2 * b] = oi;
+        out_ij[2 * b + 1] = oj;
+    }
+}
+
 int pdo_max_threads(void)
 {
 #ifdef _OPENMP

@@ -46,6 +46,8 @@ class Oracle:
         L.pdo_detect_separable.argtypes = [p, i, i, C.c_int64, i, d, i, i, i, i, i, i, p, p, p, i]
         L.pdo_detect_batch_dense.restype = None
         L.pdo_detect_batch_dense.argtypes = [p, C.c_int64, i, i, i, C.c_int64, i, p, i, i, i, p, p, i]
+        L.pdo_detect_batch_par.restype = None
+        L.pdo_detect_batch_par.argtypes = [p, C.c_int64, i, i, i, C.c_int64, i, p, d, i, i, i, i, p, p, i, i]
         L.pdo_max_threads.restype = i
 
     # --- scalars (src/PawsomeTracker.jl:30, :64-68; ImageFiltering Kernel.DoG) ---
@@ -112,6 +114,19 @@ class Oracle:
         self.lib.pdo_detect_batch_dense(frames.ctypes.data, h * w, n, h, w, w, int(fill),
                                         K.ctypes.data, K.shape[0], radii[0], radii[1],
                                         g.ctypes.data, out.ctypes.data, nthreads)
+        return out
+
+
+    def detect_batch_par(self, frames, fill, K, sigma, darker, radii, guesses, separable=False, nthreads=0):
+        """n windows, threads split across windows (each window single-threaded)."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, h, w = frames.shape
+        K = np.asfortranarray(K, np.float64)
+        g = np.ascontiguousarray(guesses, np.int32)
+        out = np.empty((n, 2), np.int32)
+        self.lib.pdo_detect_batch_par(frames.ctypes.data, h * w, n, h, w, w, int(fill), K.ctypes.data,
+                                      float(sigma), int(bool(darker)), K.shape[0], radii[0], radii[1],
+                                      g.ctypes.data, out.ctypes.data, int(bool(separable)), nthreads)
         return out
 
 
