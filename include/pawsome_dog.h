@@ -124,6 +124,16 @@ int pdog_detect_batch(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_st
 int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride,
                      const int32_t guess[2], int32_t out_ij[2], float *h_resp);
 
+/* n independent applications on frames in HOST memory — the batch form of the ingest step
+ * `read!(vid, trckr.img.data)` (src/PawsomeTracker.jl:166) followed by the functor (:55-62).
+ * All pointers are HOST pointers (pageable is fine); arguments as pdog_detect_batch.  Only each
+ * window's padded tile crosses PCIe: host threads (PDOG_HOST_THREADS, default min(16, cores)) pack
+ * tiles into pinned staging, chunked copies overlap the kernels.  Synchronous; positions are the
+ * ones pdog_detect_batch returns for the same frames on the device.  PDOG_E_RANGE as pdog_detect_host. */
+int pdog_detect_batch_host(pdog_tracker *t, const uint8_t *h_frames, int64_t frame_stride,
+                           int64_t row_stride, int n_frames, const int32_t *h_frame_index,
+                           const int32_t *h_guesses, int n, int32_t *h_out_ij);
+
 /* The intended frame loop, src/PawsomeTracker.jl:163-169 (:167):
  * out[0] = functor(frame 0, start_guess); out[k] = functor(frame k, out[k-1]).
  * d_frames / d_out_ij are device pointers; start_guess is a host pointer. */

@@ -68,6 +68,27 @@ class BatchTracker:
             C.c_void_p(resp.data_ptr()) if want_resp else None))
         return (out, resp) if want_resp else out
 
+    def detect_host(self, frames, guesses, frame_index=None):
+        """The same n applications on frames in HOST memory (numpy uint8 [nf, h, w], the layout
+        `read!(vid, trckr.img.data)`, src/PawsomeTracker.jl:166, produces): only the window tiles are uploaded,
+        in chunks that overlap the kernels.  guesses int32 [n, 2]; returns numpy int32 [n, 2].  Synchronous."""
+        import numpy as np
+        self.use_torch_stream()
+        assert frames.dtype == np.uint8 and frames.ndim == 3 and frames.strides[2] == 1
+        assert frames.shape[1] == self.frame_h and frames.shape[2] == self.frame_w
+        g = np.ascontiguousarray(guesses, np.int32)
+        n = g.shape[0]
+        out = np.empty((n, 2), np.int32)
+        fi = None
+        if frame_index is not None:
+            fi_arr = np.ascontiguousarray(frame_index, np.int32)
+            assert fi_arr.shape == (n,)
+            fi = C.c_void_p(fi_arr.ctypes.data)
+        _lib.check(_lib.lib().pdog_detect_batch_host(
+            self._h, C.c_void_p(frames.ctypes.data), frames.strides[0], frames.strides[1], frames.shape[0], fi,
+            C.c_void_p(g.ctypes.data), n, C.c_void_p(out.ctypes.data)))
+        return out
+
     def detect_chain(self, frames, start_guess, out=None):
         """The serial chain of src/PawsomeTracker.jl:163-169 on device-resident frames."""
         import torch

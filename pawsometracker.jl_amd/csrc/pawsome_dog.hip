@@ -14,8 +14,11 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -170,6 +173,15 @@ struct pdog_tracker {
     int32_t *d_small = nullptr; // [0..1] guess, [2..3] result
     int32_t *h_pinned = nullptr; // pinned mirror of d_small: the host path's 8-byte copies skip the pageable staging
     float *d_resp = nullptr;
+    // host-batch ingest (pdog_detect_batch_host): rotating pinned staging / device tile slots
+    static constexpr int kIngestSlots = 3;
+    uint8_t *h_stage[kIngestSlots] = {nullptr, nullptr, nullptr};
+    uint8_t *d_tiles[kIngestSlots] = {nullptr, nullptr, nullptr};
+    size_t ingest_slot_bytes = 0;
+    int32_t *d_ingest_guess = nullptr, *d_ingest_out = nullptr, *h_ingest_out = nullptr;
+    int ingest_cap = 0, ingest_guess_cap = 0;
+    hipStream_t h2d_stream = nullptr;
+    hipEvent_t ev_h2d[kIngestSlots] = {nullptr, nullptr, nullptr}, ev_used[kIngestSlots] = {nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -286,9 +298,11 @@ int ensure_capacity(pdog_tracker *t, int n)
 
 int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
                   const int32_t *d_frame_index, const int32_t *d_guesses, int n, int32_t *d_out_ij,
-                  float *d_out_resp)
+                  float *d_out_resp, int fh_override = 0, int fw_override = 0)
 {
     const Variant &v = *t->var;
+    // frames of another size than the tracker's (the packed window tiles of pdog_detect_batch_host)
+    const int FH = fh_override ? fh_override : t->fh, FW = fw_override ? fw_override : t->fw;
     LaunchGeo g;
     g.frames = d_frames;
     g.frame_stride = frame_stride;
@@ -298,7 +312,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     g.resp = d_out_resp;
     g.part_val = t->d_part_val;
     g.part_idx = t->d_part_idx;
-    g.fh = t->fh; g.fw = t->fw; g.r1 = t->r1; g.r2 = t->r2; g.n1 = t->n1; g.n2 = t->n2;
+    g.fh = FH; g.fw = FW; g.r1 = t->r1; g.r2 = t->r2; g.n1 = t->n1; g.n2 = t->n2;
     g.L = t->L; g.fill = t->fill; g.nstrips = t->nstrips; g.n = n;
     g.RR = v.ring(t->L);
     g.pitchA = v.pa(t->L);
@@ -365,7 +379,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         }
         hipLaunchKernelGGL(dog_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, t->stream,
                            t->d_part_val, t->d_part_idx, d_guesses, d_out_ij, n, g.nslots,
-                           t->r1, t->r2, t->n1, t->fh, t->fw);
+                           t->r1, t->r2, t->n1, FH, FW);
         HIP_TRY(hipGetLastError());
         return PDOG_OK;
     }
@@ -393,7 +407,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     if (t->nthin) HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0)); // join before the strip combine
     hipLaunchKernelGGL(dog_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, t->stream,
                        t->d_part_val, t->d_part_idx, d_guesses, d_out_ij, n, g.nslots,
-                       t->r1, t->r2, t->n1, t->fh, t->fw);
+                       t->r1, t->r2, t->n1, FH, FW);
     HIP_TRY(hipGetLastError());
     return PDOG_OK;
 }
@@ -572,6 +586,16 @@ int pdog_destroy(pdog_tracker *t)
     if (t->d_V) (void)hipFree(t->d_V);
     if (t->d_dc) (void)hipFree(t->d_dc);
     if (t->d_chain_tmp) (void)hipFree(t->d_chain_tmp);
+    if (t->h2d_stream) { (void)hipStreamSynchronize(t->h2d_stream); (void)hipStreamDestroy(t->h2d_stream); }
+    for (int k = 0; k < pdog_tracker::kIngestSlots; ++k) {
+        if (t->h_stage[k]) (void)hipHostFree(t->h_stage[k]);
+        if (t->d_tiles[k]) (void)hipFree(t->d_tiles[k]);
+        if (t->ev_h2d[k]) (void)hipEventDestroy(t->ev_h2d[k]);
+        if (t->ev_used[k]) (void)hipEventDestroy(t->ev_used[k]);
+    }
+    if (t->d_ingest_guess) (void)hipFree(t->d_ingest_guess);
+    if (t->d_ingest_out) (void)hipFree(t->d_ingest_out);
+    if (t->h_ingest_out) (void)hipHostFree(t->h_ingest_out);
     if (t->aux_stream) { (void)hipStreamSynchronize(t->aux_stream); (void)hipStreamDestroy(t->aux_stream); }
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
@@ -694,6 +718,187 @@ int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride
 }
 
 } // extern "C"
+
+namespace {
+
+// One window's padded tile, (n1+l-1) rows of `pitch` bytes: the frame rectangle the functor reads, with the
+// PaddedView fill (:48) materialised wherever the rectangle leaves the frame.  Tile row a, column b is the
+// padded frame at 1-based (g1 - r1 - l÷2 + a, g2 - r2 - l÷2 + b).
+void pack_tile(const pdog_tracker *t, const uint8_t *frame, int64_t row_stride, int g1, int g2, uint8_t *dst, int pitch)
+{
+    const int hw = t->L >> 1, th = t->n1 + 2 * hw, tw = t->n2 + 2 * hw;
+    const int i0 = g1 - t->r1 - hw - 1, j0 = g2 - t->r2 - hw - 1;   // 0-based frame coordinates of tile (0, 0)
+    const int jl = std::min(tw, std::max(0, -j0));                 // columns left of the frame
+    const int jr = std::max(jl, std::min(tw, t->fw - j0));         // first column right of the frame
+    for (int a = 0; a < th; ++a) {
+        uint8_t *row = dst + (size_t)a * pitch;
+        const int gi = i0 + a;
+        if (gi < 0 || gi >= t->fh) { std::memset(row, t->fill, (size_t)pitch); continue; }
+        if (jl) std::memset(row, t->fill, (size_t)jl);
+        if (jr > jl) std::memcpy(row + jl, frame + (size_t)gi * row_stride + (j0 + jl), (size_t)(jr - jl));
+        if (pitch > jr) std::memset(row + jr, t->fill, (size_t)(pitch - jr));
+    }
+}
+
+int ingest_threads()
+{
+    if (const char *e = std::getenv("PDOG_HOST_THREADS")) return std::max(1, std::min(64, std::atoi(e)));
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(16u, hc ? hc : 1u));
+}
+
+} // namespace
+
+// Frame ingest for batches: the frames are in HOST memory, as `read!(vid, trckr.img.data)`
+// (:166) leaves them.  Only each window's padded tile crosses PCIe (cfg3: 103 KB instead of the 2 MB
+// frame): host threads pack the tiles of a chunk into pinned staging, one async copy per chunk moves them
+// on a copy stream, and the kernels of chunk c run beside the copy of chunk c+1 and the packing of c+2.
+// On the device every tile is a frame of its own with the guess at its centre, so the kernels see exactly
+// the pixel values the padded frame would give them; the tile-local result is mapped back and clamped to
+// the frame (:60-61) on the host.
+extern "C" int pdog_detect_batch_host(pdog_tracker *t, const uint8_t *h_frames, int64_t frame_stride, int64_t row_stride,
+                                      int n_frames, const int32_t *h_frame_index, const int32_t *h_guesses, int n,
+                                      int32_t *h_out_ij)
+{
+    if (!t) return fail(PDOG_E_ARG, "pdog_detect_batch_host: null tracker");
+    if (n == 0) return PDOG_OK;
+    if (!h_frames || !h_guesses || !h_out_ij) return fail(PDOG_E_ARG, "pdog_detect_batch_host: null pointer");
+    if (n < 0 || n_frames <= 0 || row_stride < t->fw || frame_stride < 0) return fail(PDOG_E_ARG, "pdog_detect_batch_host: bad size/stride");
+    if (!h_frame_index && n > n_frames) return fail(PDOG_E_ARG, "pdog_detect_batch_host: more windows than frames and no frame index");
+    const int hw = t->L >> 1;
+    for (int b = 0; b < n; ++b) {
+        const int g1 = h_guesses[2 * b], g2 = h_guesses[2 * b + 1];
+        if (g1 < -hw || g1 > t->fh + hw + 1 || g2 < -hw || g2 > t->fw + hw + 1)
+            return fail(PDOG_E_RANGE, "pdog_detect_batch_host: guess outside the padded frame (reference: BoundsError)");
+        if (h_frame_index && (h_frame_index[b] < 0 || h_frame_index[b] >= n_frames))
+            return fail(PDOG_E_ARG, "pdog_detect_batch_host: frame index out of range");
+    }
+    HIP_TRY(hipSetDevice(t->device));
+    const int th = t->n1 + 2 * hw, tw = t->n2 + 2 * hw, pitch = round_up(tw, 16);
+    const size_t tile_bytes = (size_t)th * pitch;
+    // chunk: ≈32 MB of tiles, at least 64 windows (the batch kernels want ≥ 1000 strip-waves when they can get them)
+    int chunk = (int)std::max<size_t>(64, ((size_t)32 << 20) / tile_bytes);
+    if (const char *e = std::getenv("PDOG_INGEST_CHUNK")) chunk = std::max(1, std::atoi(e));
+    chunk = std::min(chunk, n);
+    constexpr int NS = pdog_tracker::kIngestSlots;
+    if (!t->h2d_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&t->h2d_stream, hipStreamNonBlocking));
+        for (int k = 0; k < NS; ++k) {
+            HIP_TRY(hipEventCreateWithFlags(&t->ev_h2d[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&t->ev_used[k], hipEventDisableTiming));
+        }
+    }
+    if (t->ingest_slot_bytes < tile_bytes * chunk) {
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        HIP_TRY(hipStreamSynchronize(t->h2d_stream));
+        for (int k = 0; k < NS; ++k) {
+            if (t->h_stage[k]) (void)hipHostFree(t->h_stage[k]);
+            if (t->d_tiles[k]) (void)hipFree(t->d_tiles[k]);
+            t->h_stage[k] = nullptr; t->d_tiles[k] = nullptr;
+        }
+        t->ingest_slot_bytes = 0;
+        for (int k = 0; k < NS; ++k) {
+            HIP_TRY(hipHostMalloc((void **)&t->h_stage[k], tile_bytes * chunk, hipHostMallocDefault));
+            HIP_TRY(hipMalloc(&t->d_tiles[k], tile_bytes * chunk));
+        }
+        t->ingest_slot_bytes = tile_bytes * chunk;
+    }
+    if (t->ingest_guess_cap < chunk) {
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        if (t->d_ingest_guess) (void)hipFree(t->d_ingest_guess);
+        t->d_ingest_guess = nullptr; t->ingest_guess_cap = 0;
+        HIP_TRY(hipMalloc(&t->d_ingest_guess, sizeof(int32_t) * 2 * (size_t)chunk));
+        std::vector<int32_t> centre(2 * (size_t)chunk);
+        for (int b = 0; b < chunk; ++b) { centre[2 * b] = t->r1 + hw + 1; centre[2 * b + 1] = t->r2 + hw + 1; }
+        HIP_TRY(hipMemcpy(t->d_ingest_guess, centre.data(), sizeof(int32_t) * centre.size(), hipMemcpyHostToDevice));
+        t->ingest_guess_cap = chunk;
+    }
+    if (t->ingest_cap < n) {
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        if (t->d_ingest_out) (void)hipFree(t->d_ingest_out);
+        if (t->h_ingest_out) (void)hipHostFree(t->h_ingest_out);
+        t->d_ingest_out = nullptr; t->h_ingest_out = nullptr; t->ingest_cap = 0;
+        HIP_TRY(hipMalloc(&t->d_ingest_out, sizeof(int32_t) * 2 * (size_t)n));
+        HIP_TRY(hipHostMalloc((void **)&t->h_ingest_out, sizeof(int32_t) * 2 * (size_t)n, hipHostMallocDefault));
+        t->ingest_cap = n;
+    }
+    if (chunk > t->cap_windows) {
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        if (int rc = ensure_capacity(t, chunk)) return rc;
+    }
+
+    const int nchunks = (n + chunk - 1) / chunk;
+    std::atomic<int> next{0}, submitted{0}, failed{0};
+    std::vector<std::atomic<int>> packed(nchunks);
+    for (auto &p : packed) p.store(0);
+    auto worker = [&]() {
+        (void)hipSetDevice(t->device);
+        int waited_for = -1; // highest chunk whose slot this thread has seen released
+        for (;;) {
+            const int b = next.fetch_add(1);
+            if (b >= n || failed.load()) return;
+            const int c = b / chunk;
+            if (c >= NS && waited_for < c) {
+                // the slot was last used by chunk c - NS: wait until its copy has been enqueued, then done
+                while (submitted.load(std::memory_order_acquire) <= c - NS) {
+                    if (failed.load()) return;
+                    std::this_thread::yield();
+                }
+                if (hipEventSynchronize(t->ev_h2d[c % NS]) != hipSuccess) { failed.store(1); return; }
+                waited_for = c;
+            }
+            const int f = h_frame_index ? h_frame_index[b] : b;
+            pack_tile(t, h_frames + (int64_t)f * frame_stride, row_stride, h_guesses[2 * b], h_guesses[2 * b + 1],
+                      t->h_stage[c % NS] + (size_t)(b - c * chunk) * tile_bytes, pitch);
+            packed[c].fetch_add(1, std::memory_order_release);
+        }
+    };
+    const int nthreads = std::min(ingest_threads(), n);
+    std::vector<std::thread> pool;
+    for (int k = 0; k < nthreads; ++k) pool.emplace_back(worker);
+    int rc = PDOG_OK;
+    const bool trace = std::getenv("PDOG_INGEST_TRACE") != nullptr; // diagnostic: where the wall time of a call goes
+    const auto t_begin = std::chrono::steady_clock::now();
+    double wait_pack_ms = 0;
+    for (int c = 0; c < nchunks && rc == PDOG_OK; ++c) {
+        const int w0 = c * chunk, nw = std::min(chunk, n - w0), slot = c % NS;
+        const auto tw0 = std::chrono::steady_clock::now();
+        while (packed[c].load(std::memory_order_acquire) < nw && !failed.load()) std::this_thread::yield();
+        wait_pack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+        if (failed.load()) { rc = fail(PDOG_E_HIP, "pdog_detect_batch_host: event wait failed in a packing thread"); break; }
+        hipError_t e = hipSuccess;
+        if (c >= NS) e = hipStreamWaitEvent(t->h2d_stream, t->ev_used[slot], 0); // kernels of chunk c - NS are done with the device slot
+        if (e == hipSuccess) e = hipMemcpyAsync(t->d_tiles[slot], t->h_stage[slot], tile_bytes * nw, hipMemcpyHostToDevice, t->h2d_stream);
+        if (e == hipSuccess) e = hipEventRecord(t->ev_h2d[slot], t->h2d_stream);
+        submitted.store(c + 1, std::memory_order_release);
+        if (e == hipSuccess) e = hipStreamWaitEvent(t->stream, t->ev_h2d[slot], 0);
+        if (e != hipSuccess) { rc = fail(PDOG_E_HIP, std::string("pdog_detect_batch_host: ") + hipGetErrorString(e)); break; }
+        rc = launch_detect(t, t->d_tiles[slot], (int64_t)tile_bytes, pitch, nullptr, t->d_ingest_guess, nw,
+                           t->d_ingest_out + 2 * (size_t)w0, nullptr, th, tw);
+        if (rc == PDOG_OK && hipEventRecord(t->ev_used[slot], t->stream) != hipSuccess)
+            rc = fail(PDOG_E_HIP, "pdog_detect_batch_host: hipEventRecord failed");
+    }
+    if (rc != PDOG_OK) { failed.store(1); submitted.store(nchunks + NS); }
+    for (auto &th_ : pool) th_.join();
+    if (rc != PDOG_OK) { (void)hipStreamSynchronize(t->h2d_stream); (void)hipStreamSynchronize(t->stream); return rc; }
+    const auto t_submitted = std::chrono::steady_clock::now();
+    HIP_TRY(hipMemcpyAsync(t->h_ingest_out, t->d_ingest_out, sizeof(int32_t) * 2 * (size_t)n, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    if (trace) {
+        const auto t_end = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "pdog ingest: %d windows, %d chunks of %d, %d threads: submit loop %.2f ms (waiting for packers %.2f ms), drain %.2f ms\n",
+                     n, nchunks, chunk, nthreads, std::chrono::duration<double, std::milli>(t_submitted - t_begin).count(), wait_pack_ms,
+                     std::chrono::duration<double, std::milli>(t_end - t_submitted).count());
+    }
+    for (int b = 0; b < n; ++b) {
+        // tile-local 1-based (p, q)  ->  padded-frame index  ->  clamp (:60-61)
+        const int i = h_guesses[2 * b] - t->r1 - hw + t->h_ingest_out[2 * b] - 1;
+        const int j = h_guesses[2 * b + 1] - t->r2 - hw + t->h_ingest_out[2 * b + 1] - 1;
+        h_out_ij[2 * b] = std::min(std::max(i, 1), t->fh);
+        h_out_ij[2 * b + 1] = std::min(std::max(j, 1), t->fw);
+    }
+    return PDOG_OK;
+}
 
 namespace {
 

@@ -455,3 +455,44 @@ def test_full_size_properties_other_configs(pt, oracle, cfg):
     g = np.array([[fh // 2, fw // 2]], np.int32)
     exp = np.array([[max(1, fh // 2 - radii[0]), max(1, fw // 2 - radii[1])]], np.int32)
     assert np.array_equal(_batch(pt, flat, g, tw, ws, True, 128), exp)                # (ii) flat window
+
+
+@pytest.mark.parametrize("tw,ws,chunk", [(25, (256, 256), 64), (25, (45, 45), 0), (10, (21, 33), 16), (120, (205, 205), 8)])
+def test_host_batch_ingest_equals_device_batch(pt, oracle, tw, ws, chunk, monkeypatch):
+    """pdog_detect_batch_host (frames in host memory, only the window tiles uploaded, chunks rotating through
+    three staging slots) returns the positions pdog_detect_batch returns for the same frames on the device;
+    guesses up to l÷2 outside the frame, shared frames through frame_index, padded row stride."""
+    from oracle import synth
+    fh, fw = 300, 420
+    radii = (ws[0] // 2, ws[1] // 2)
+    nf = 40
+    frames, guesses, _ = synth.make_batch(nf, fh, fw, tw, radii, True, seed=33, noise=3)
+    wide = np.zeros((nf, fh, fw + 24), np.uint8)
+    wide[:, :, :fw] = frames
+    strided = wide[:, :, :fw]                                   # row stride fw + 24
+    rng = np.random.default_rng(5)
+    n = 200
+    fi = rng.integers(0, nf, n).astype(np.int32)
+    hw = oracle.kernel_len(oracle.sigma(tw)) // 2
+    g = guesses[fi] + rng.integers(-radii[0], radii[0] + 1, (n, 2)).astype(np.int32)
+    g[:8] = [[-hw, -hw], [fh + hw + 1, fw + hw + 1], [1, fw], [fh, 1], [-hw, fw + hw + 1], [fh + hw + 1, -hw], [1, 1], [fh, fw]]
+    g = np.clip(g, [-hw, -hw], [fh + hw + 1, fw + hw + 1]).astype(np.int32)
+    fill = oracle.mode_u8(frames[0])
+    if chunk:
+        monkeypatch.setenv("PDOG_INGEST_CHUNK", str(chunk))
+    bt = pt.BatchTracker(fh, fw, tw, ws, True, fill)
+    got = bt.detect_host(strided, g, fi)
+    again = bt.detect_host(strided, g[:3], fi[:3])              # a second, smaller call reuses the slots
+    no_index = bt.detect_host(strided, g[:nf])                  # window b -> frame b
+    assert bt.detect_host(strided, g[:0]).shape == (0, 2)
+    with pytest.raises(pt.PdogError):
+        bad = g[:2].copy(); bad[1, 0] = fh + hw + 2
+        bt.detect_host(strided, bad, fi[:2])
+    bt.close()
+    exp = _batch(pt, frames, g, tw, ws, True, fill, frame_index=fi)
+    assert np.array_equal(got, exp)
+    assert np.array_equal(again, exp[:3])
+    assert np.array_equal(no_index, _batch(pt, frames, g[:nf], tw, ws, True, fill))
+    K = oracle.dog_kernel(oracle.sigma(tw), True)
+    for b in range(0, n, 37 if tw < 100 else 97):               # and a few against the oracle directly
+        assert tuple(got[b]) == oracle.detect(frames[fi[b]], fill, K, radii, g[b])
