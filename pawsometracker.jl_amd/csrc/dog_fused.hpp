@@ -1,0 +1,307 @@
+// dog_fused.hpp — DoG + argmax for windows whose whole padded tile fits in one CU's LDS, ONE workgroup per
+// window and ONE launch per batch or per chain (reference functor /root/reference/src/PawsomeTracker.jl:55-62,
+// frame loop :163-169).
+//
+// This is the latency kernel: the reference's own use is one `Tracker` call per decoded frame with the default
+// window (45×45 for target_width 25, `guess_window_size` :64-68), where the batch kernels' four launches per
+// frame cost more than the arithmetic (0.9 M FMA).  Here the DC level, both separable passes, the peak search,
+// the index map and the clamp (:56-61) run inside a single 1024-thread workgroup with the row-pass result kept
+// transposed in LDS, and a chain of frames (`ij[k] = trckr(ij[k-1])`, :167) is a loop inside the kernel: one
+// barrier-separated pipeline per frame, no launch and no host round trip between frames.
+//
+//   tile (n1+l−1)×(n2+l−1) u8 → LDS f32 (pixel − dc)                     coalesced, fill outside the frame (:48)
+//   row pass   task = (tile row a, group of PR outputs)  → RT[x][a] (f2: both Gaussians) in LDS
+//   column pass task = (window column x, group of PC rows) on RT rows → D, running first maximum
+//   workgroup reduction (ties → smallest column-major index, findmax :59) → clamped (row, col)
+//
+// The arithmetic per output is that of dog_twopass.hpp (row pass: symmetric pairs k ascending, then the centre
+// tap; column pass: k ascending), identical for every output, so flat regions tie exactly.
+#pragma once
+#include "dog_twopass.hpp"
+
+namespace pdog {
+
+struct FusedGeo {
+    LaunchGeo g;
+    int NA, TWin;        // padded tile rows / columns
+    int pitchA, pitchV;  // LDS pitches: tile rows (floats), RT rows (f2); odd
+    int cshift;          // staging: 2^cshift ≥ ⌈TWin/4⌉ threads per tile row, 4 pixels each
+    int pr, pc;          // outputs per task in the row / column pass, chosen per geometry so that the tasks fill the 1024 threads
+    int chain_len;       // 1: n independent windows.  > 1: clip b = frames b·chain_len …, frame k > 0 starts at frame k−1's result
+    int32_t *out_ij;     // [n][chain_len][2], clamped to the frame
+};
+
+constexpr int FUSED_NT = 1024, FUSED_PMAX = 8, FUSED_U = 8;
+
+// LDS pitches (odd ⇒ conflict-free strided reads) with room for the sliding windows of the last, partly masked
+// output group of up to FUSED_PMAX outputs and their one-block prefetch
+__host__ __device__ constexpr int fused_pitch_a(int n2, int L) { return ((n2 + FUSED_PMAX - 1) / FUSED_PMAX * FUSED_PMAX + L + FUSED_U + 1) | 1; }
+__host__ __device__ constexpr int fused_pitch_v(int n1, int L) { return ((n1 + FUSED_PMAX - 1) / FUSED_PMAX * FUSED_PMAX + L + 24 + 1) | 1; } // + 24: the compile-time-l column pass reads whole 16-tap blocks
+__host__ __device__ constexpr size_t fused_a_bytes(int n1, int n2, int L) { return ((size_t)(n1 + L - 1) * fused_pitch_a(n2, L) * 4 + 15) / 16 * 16; }
+__host__ __device__ constexpr size_t fused_lds_bytes(int n1, int n2, int L) { return fused_a_bytes(n1, n2, L) + (size_t)n2 * fused_pitch_v(n1, L) * 8; }
+
+// PR outputs of one tile row: out[o] = Σ_k (g₊[k], g₋[k]) · in[o+k], symmetric pairs first (k ascending), centre last.
+// Runtime kernel length, blocks of U taps.  (Compile-time-l instances with the tap loop fully unrolled were
+// tried for l = 65: 400 SGPR + 300 VGPR spills under the 128-VGPR budget of a 1024-thread workgroup, 2× slower.)
+template <int P, int U>
+__device__ __forceinline__ void fused_row_task(const float *in, int L, tap_ptr taps, f2 (&acc)[P])
+{
+    const int H = L >> 1;
+    auto ld = [&](int i) { return in[i]; };
+#pragma unroll
+    for (int o = 0; o < P; ++o) acc[o] = f2{0.f, 0.f};
+    float lo[P + U - 1], hi[P + U - 1];
+#pragma unroll
+    for (int j = 0; j < P + U - 1; ++j) {
+        lo[j] = ld(j);
+        hi[j] = ld(L - U + j);
+    }
+    int k0 = 0;
+    for (; k0 + U <= H; k0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const f2 t = taps[k0 + u];
+#pragma unroll
+            for (int o = 0; o < P; ++o) acc[o] = fma_bcast(lo[o + u] + hi[o + (U - 1) - u], t, acc[o]);
+        }
+#pragma unroll
+        for (int j = 0; j < P - 1; ++j) lo[j] = lo[j + U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) lo[P - 1 + j] = ld(k0 + U + (P - 1) + j);
+#pragma unroll
+        for (int j = P + U - 2; j >= U; --j) hi[j] = hi[j - U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) hi[j] = ld(L - U - (k0 + U) + j);
+    }
+    for (; k0 < H; ++k0) {
+        const f2 t = taps[k0];
+#pragma unroll
+        for (int o = 0; o < P; ++o) acc[o] = fma_bcast(ld(o + k0) + ld(o + L - 1 - k0), t, acc[o]);
+    }
+    const f2 t = taps[H];
+#pragma unroll
+    for (int o = 0; o < P; ++o) acc[o] = fma_bcast(ld(o + H), t, acc[o]);
+}
+
+// PC outputs of one window column: acc[o] = Σ_k (s·g₊[k], −s·g₋[k]) ∘ RT[x][o+k], k ascending
+template <int P, int U>
+__device__ __forceinline__ void fused_col_task(const f2 *a, int L, tap_ptr taps, f2 (&acc)[P])
+{
+    auto ld = [&](int i) { return a[i]; };
+#pragma unroll
+    for (int o = 0; o < P; ++o) acc[o] = f2{0.f, 0.f};
+    f2 win[P + U - 1];
+#pragma unroll
+    for (int j = 0; j < P + U - 1; ++j) win[j] = ld(j);
+    int k0 = 0;
+    for (; k0 + U <= L; k0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const f2 t = taps[k0 + u];
+#pragma unroll
+            for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[o + u], t, acc[o]);
+        }
+        // the next block's values are loaded straight into the window (P − 1 register moves per block instead of
+        // P − 1 + U); the other waves of the SIMD cover the LDS latency
+#pragma unroll
+        for (int j = 0; j < P - 1; ++j) win[j] = win[j + U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) win[P - 1 + j] = ld(k0 + U + (P - 1) + j);
+    }
+    for (; k0 < L; ++k0) {
+        const f2 t = taps[k0];
+#pragma unroll
+        for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[o], t, acc[o]);
+#pragma unroll
+        for (int j = 0; j < P + U - 2; ++j) win[j] = win[j + 1];
+    }
+}
+
+// DIAG != 0 (diagnostic builds only): thread 0 of block 0 stamps the phase boundaries of every frame into g.resp
+// (16 floats per frame: shader cycles since the frame's start at 0 samples reduced (wave 0), 4 after the barrier,
+// 1 tile staged, 2 row pass, 5 column pass + wave peak (wave 0), 6 after the barrier, 3 end of frame; then the same
+// in 100 MHz ticks) instead of the response.
+template <bool RESP, int DIAG = 0>
+__global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, const f2 *__restrict__ taps_row,
+                                                             const f2 *__restrict__ taps_col)
+{
+    const LaunchGeo &g = fg.g;
+    constexpr int NT = FUSED_NT, NW = NT / 64, U = FUSED_U;
+    const int L = g.L, hw = L >> 1, NA = fg.NA;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *A = reinterpret_cast<float *>(smem);
+    f2 *Vs = reinterpret_cast<f2 *>(smem + fused_a_bytes(g.n1, g.n2, L));
+    __shared__ int s_sum[NW];
+    __shared__ float s_val[NW];
+    __shared__ int s_idx[NW];
+    __shared__ int s_guess[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const tap_ptr trow = as_taps(taps_row), tcol = as_taps(taps_col);
+
+    // tile columns c ≥ TWin and RT columns a ≥ NA are only ever read by the sliding windows of masked outputs: zero once
+    for (int r = wave; r < NA; r += NW)
+        for (int c = fg.TWin + lane; c < fg.pitchA; c += 64) A[r * fg.pitchA + c] = 0.f;
+    for (int x = wave; x < g.n2; x += NW)
+        for (int c = NA + lane; c < fg.pitchV; c += 64) Vs[x * fg.pitchV + c] = f2{0.f, 0.f};
+
+    int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
+    for (int k = 0; k < fg.chain_len; ++k) {
+        const long long fidx = fg.chain_len > 1 ? (long long)b * fg.chain_len + k : (g.frame_index ? g.frame_index[b] : b);
+        const uint8_t *__restrict__ frame = g.frames + fidx * g.frame_stride;
+        const int ti0 = g1 - g.r1 - 1 - hw, wj0 = g2 - g.r2 - 1 - hw;
+        unsigned long long dc0 = 0, dr0 = 0;
+        auto stamp = [&](int i) {
+            if (DIAG && tid == 0 && b == 0) {
+                g.resp[16 * k + i] = (float)(__builtin_amdgcn_s_memtime() - dc0);
+                g.resp[16 * k + 8 + i] = (float)(__builtin_amdgcn_s_memrealtime() - dr0);
+            }
+        };
+        if (DIAG) { dc0 = __builtin_amdgcn_s_memtime(); dr0 = __builtin_amdgcn_s_memrealtime(); }
+        // ---- per-window DC level (see dog_kernels.hpp) and staging.  Thread → (tile row tid >> cshift, 4-byte column
+        // group tid & (2^cshift − 1)): one unaligned dword load per 4 pixels, no division.  The thread's DC sample
+        // (one of the 32×32 grid of dc_sample_sum) and its first SU dwords are requested together — one memory round
+        // trip — and the tile goes to LDS as (float)(pixel − dc) once the integer sample sum has been reduced.
+        // Loads are unconditional at addresses clamped into the frame and the fill is selected afterwards (no branch
+        // between two loads: all of a batch are in flight together); a clamped dword still holds every in-frame
+        // byte its group needs, at a shifted position ----
+        {
+            constexpr int SU = 4; // rows per thread and batch: the default 45×45 window (109 tile rows, 32 per pass) needs exactly 4
+            const int q = tid & ((1 << fg.cshift) - 1), sr0 = tid >> fg.cshift, srstep = NT >> fg.cshift;
+            const int c0 = 4 * q, gj0 = wj0 + c0, gj0c = min(max(gj0, 0), g.fw - 4);
+            const uint8_t *colp = frame + gj0c;
+            auto load_batch = [&](int r0, uint32_t (&v)[SU]) {
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int gi = ti0 + r0 + u * srstep;
+                    __builtin_memcpy(&v[u], colp + (long long)min(max(gi, 0), g.fh - 1) * g.row_stride, 4);
+                }
+            };
+            int samp;
+            {
+                const int si = ti0 + (int)(((long long)(tid >> 5) * NA) >> 5), sj = wj0 + (int)(((long long)(tid & 31) * fg.TWin) >> 5);
+                samp = frame[(long long)min(max(si, 0), g.fh - 1) * g.row_stride + min(max(sj, 0), g.fw - 1)];
+                if (!(si >= 0 && si < g.fh && sj >= 0 && sj < g.fw)) samp = g.fill;
+            }
+            uint32_t v[SU];
+            load_batch(sr0, v);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) samp += __shfl_xor(samp, off, 64);
+            if (lane == 0) s_sum[wave] = samp;
+            stamp(0);
+            __syncthreads();
+            stamp(4);
+            int total = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) total += s_sum[w];
+            const int dc = dc_from_sum(total, g.fill);
+            for (int r0 = sr0; r0 < NA; r0 += srstep * SU) {
+                if (r0 != sr0) load_batch(r0, v);
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int r = r0 + u * srstep, gi = ti0 + r;
+                    const bool rowok = gi >= 0 && gi < g.fh;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int gj = gj0 + i;
+                        const int px = (rowok && gj >= 0 && gj < g.fw) ? (int)((v[u] >> (8 * ((gj - gj0c) & 3))) & 0xffu) : g.fill;
+                        if (c0 + i < fg.TWin && r < NA) A[r * fg.pitchA + c0 + i] = (float)(px - dc);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        stamp(1);
+        // ---- row pass → RT[x][a] ----
+        {
+            const int ngx = (g.n2 + fg.pr - 1) / fg.pr, ntask = NA * ngx;
+            auto run = [&](auto Pc) {
+                constexpr int PR = decltype(Pc)::value;
+                for (int task = tid; task < ntask; task += NT) {
+                    const int gx = task / NA, a = task - gx * NA, xb = gx * PR;
+                    f2 acc[PR];
+                    fused_row_task<PR, U>(A + a * fg.pitchA + xb, L, trow, acc);
+#pragma unroll
+                    for (int o = 0; o < PR; ++o)
+                        if (xb + o < g.n2) Vs[(xb + o) * fg.pitchV + a] = acc[o];
+                }
+            };
+            switch (fg.pr) {
+            case 3: run(std::integral_constant<int, 3>{}); break;
+            case 4: run(std::integral_constant<int, 4>{}); break;
+            case 5: run(std::integral_constant<int, 5>{}); break;
+            case 6: run(std::integral_constant<int, 6>{}); break;
+            default: run(std::integral_constant<int, 8>{}); break;
+            }
+        }
+        __syncthreads();
+        stamp(2);
+        // ---- column pass + peak ----
+        float best = -__builtin_huge_valf();
+        int best_idx = 0x7fffffff;
+        {
+            const int ngy = (g.n1 + fg.pc - 1) / fg.pc, ntask = g.n2 * ngy;
+            auto run = [&](auto Pc) {
+                constexpr int PC = decltype(Pc)::value;
+                for (int task = tid; task < ntask; task += NT) {
+                    const int gy = task / g.n2, x = task - gy * g.n2, yb = gy * PC;
+                    f2 acc[PC];
+                    fused_col_task<PC, U>(Vs + x * fg.pitchV + yb, L, tcol, acc);
+#pragma unroll
+                    for (int o = 0; o < PC; ++o) {
+                        const int y = yb + o;
+                        if (y < g.n1) {
+                            const float v = acc[o].x + acc[o].y;
+                            const int lin = x * g.n1 + y;
+                            if (RESP && !DIAG) g.resp[(long long)b * g.n1 * g.n2 + lin] = v;
+                            if (v > best || (v == best && lin < best_idx)) { best = v; best_idx = lin; }
+                        }
+                    }
+                }
+            };
+            switch (fg.pc) {
+            case 2: run(std::integral_constant<int, 2>{}); break;
+            case 3: run(std::integral_constant<int, 3>{}); break;
+            case 4: run(std::integral_constant<int, 4>{}); break;
+            case 6: run(std::integral_constant<int, 6>{}); break;
+            default: run(std::integral_constant<int, 8>{}); break;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_down(best, off, 64);
+            const int oi = __shfl_down(best_idx, off, 64);
+            if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
+        }
+        if (lane == 0) { s_val[wave] = best; s_idx[wave] = best_idx; }
+        stamp(5);
+        __syncthreads();
+        stamp(6);
+        if (wave == 0) { // the 16 wave peaks: lanes 0..15 of wave 0, same tie rule
+            best = lane < NW ? s_val[lane] : -__builtin_huge_valf();
+            best_idx = lane < NW ? s_idx[lane] : 0x7fffffff;
+#pragma unroll
+            for (int off = NW / 2; off > 0; off >>= 1) {
+                const float ov = __shfl_down(best, off, 64);
+                const int oi = __shfl_down(best_idx, off, 64);
+                if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
+            }
+            if (lane == 0) {
+                const int x = best_idx / g.n1, y = best_idx - x * g.n1;
+                const int i = min(max(g1 - g.r1 + y, 1), g.fh);   // :60-61
+                const int j = min(max(g2 - g.r2 + x, 1), g.fw);
+                int32_t *o = fg.out_ij + 2 * ((long long)b * fg.chain_len + k);
+                o[0] = i;
+                o[1] = j;
+                s_guess[0] = i;
+                s_guess[1] = j;
+            }
+        }
+        __syncthreads();
+        stamp(3);
+        g1 = s_guess[0];   // :167 — the next frame's guess
+        g2 = s_guess[1];
+    }
+}
+
+} // namespace pdog

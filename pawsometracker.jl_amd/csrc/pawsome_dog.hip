@@ -9,6 +9,7 @@
 #include "dog_kernels.hpp"
 #include "dog_roll.hpp"
 #include "dog_twopass.hpp"
+#include "dog_fused.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -81,12 +82,13 @@ struct Variant {
     int twopass = 0;           // dog_twopass.hpp: vertical pass → HBM → horizontal pass (Q = this value)
     typedef void (*chain_fn)(const ChainGeo, const f2 *, const f2 *);
     chain_fn chain = nullptr;  // persistent serial-chain kernel of the roll variants
+    bool fused = false;        // dog_fused.hpp: one workgroup per window, whole tile in LDS
     int tw() const { return P * XG; }
     int ring(int L) const { return LT ? ring_rows(CH, LT, Q) : ring_rows(CH, L, Q); }
     int pa(int L) const { return pitch_a(tw() + L - 1); }
     size_t lds(int L) const
     {
-        if (twopass) return 0; // sized per window width at launch
+        if (twopass || fused) return 0; // sized per window at launch
         if (roll) return roll_lds_bytes(LT);
         return (size_t)round_up(CH * pa(L) * 4, 16) + (size_t)ring(L) * pitch_r(tw()) * sizeof(f2);
     }
@@ -117,6 +119,8 @@ const Variant kVariants[] = {
     PDOG_ROLL_VARIANT(100, 65), PDOG_ROLL_VARIANT(169, 69), PDOG_ROLL_VARIANT(173, 73), PDOG_ROLL_VARIANT(177, 77),
     // any l: two launches with the intermediate in HBM (long kernels, target_width ≳ 40)
     Variant { 200, 13, 16, 16, 16, 0, 256, nullptr, nullptr, false, nullptr, nullptr, 16 },
+    // any l, windows whose padded tile fits in LDS: one workgroup per window, one launch (latency path)
+    Variant { 300, 1, 1, 1, 1, 0, FUSED_NT, nullptr, nullptr, false, nullptr, nullptr, 0, nullptr, true },
 #ifdef PDOG_ABLATIONS
     Variant { 101, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 1>, (kernel_fn)dog_roll_kernel<65, true>, true, nullptr, nullptr },
     Variant { 102, ROLL_P, 8, ROLL_CH, ROLL_CH, 65, 64, (kernel_fn)dog_roll_kernel<65, false, 2>, (kernel_fn)dog_roll_kernel<65, true>, true, nullptr, nullptr },
@@ -150,6 +154,7 @@ struct pdog_tracker {
     int nthin = 0, thin_x0 = 0; // window columns handled by the thin-remainder kernel
     bool forced_variant = false;   // pdog_set_variant pinned the kernel: no batch-size switching
     bool small_twopass = false;    // two-pass kernels are set up and may take over small batches
+    bool fused_ok = false;         // the window's tile fits in LDS: the fused kernel takes small batches and short chains
     int hp_rows = HP_ROWS;         // RT rows (window columns) per column-pass workgroup: 16 (P = 13) or 8 (P = 7)
     int32_t *d_chain_tmp = nullptr; // [2][n_clips][2]: current guesses / step results of multi-clip chains
     int chain_tmp_cap = 0;
@@ -173,6 +178,7 @@ struct pdog_tracker {
     int32_t *d_small = nullptr; // [0..1] guess, [2..3] result
     int32_t *h_pinned = nullptr; // pinned mirror of d_small: the host path's 8-byte copies skip the pageable staging
     float *d_resp = nullptr;
+    uint8_t *h_tile = nullptr;   // pinned, device-mapped: the functor's window tile when the fused kernel reads it in place
     // host-batch ingest (pdog_detect_batch_host): rotating pinned staging / device tile slots
     static constexpr int kIngestSlots = 3;
     uint8_t *h_stage[kIngestSlots] = {nullptr, nullptr, nullptr};
@@ -186,6 +192,10 @@ struct pdog_tracker {
 
 namespace {
 
+void pack_tile(const pdog_tracker *t, const uint8_t *frame, int64_t row_stride, int g1, int g2, uint8_t *dst, int pitch);
+typedef void (*fused_fn_t)(const FusedGeo, const f2 *, const f2 *);
+fused_fn_t fused_kernel_for(int L, bool resp);
+
 // LDS row pitches of the two-pass kernels: the sliding windows (and their one-block prefetch) of the last,
 // partly masked group of 13 outputs must stay inside the zero-padded row.  nout outputs, l taps.
 int twopass_pitch(int nout, int L, int rows = HP_ROWS) { return (round_up(nout, rows == 8 ? 32 * 7 : 16 * 13) + L + 16) | 1; }
@@ -197,6 +207,10 @@ int choose_variant(pdog_tracker *t, int forced)
     for (int i = 0; i < kNumVariants; ++i) {
         const Variant &v = kVariants[i];
         if (forced >= 0 && v.id != forced) continue;
+        if (v.fused) { // never the tracker's batch kernel unless forced; small batches and chains reach it below
+            if (forced == v.id && fused_lds_bytes(t->n1, t->n2, t->L) <= kMaxLds - 1024 && t->n2 + t->L - 1 <= 4 * FUSED_NT && t->fw >= 4) best = &v;
+            continue;
+        }
         if (v.LT != 0 && v.LT != t->L) continue;
         if (v.lds(t->L) > kMaxLds) continue;
         if (forced < 0 && t->L >= 80 && !v.twopass) continue; // long kernels: two-pass path (measured 1.7× the ring kernel at l = 293)
@@ -227,6 +241,13 @@ int choose_variant(pdog_tracker *t, int forced)
     t->thin_x0 = 0;
     t->forced_variant = forced >= 0;
     t->small_twopass = false;
+    t->fused_ok = fused_lds_bytes(t->n1, t->n2, t->L) <= kMaxLds - 1024 && t->n2 + t->L - 1 <= 4 * FUSED_NT && t->fw >= 4;
+    if (t->fused_ok) {
+        for (bool resp : {false, true}) {
+            if (int rc = raise_lds_limit((const void *)fused_kernel_for(t->L, resp), fused_lds_bytes(t->n1, t->n2, t->L))) return rc;
+        }
+    }
+    if (best->fused) { t->nstrips = 1; return PDOG_OK; }
     {
         // The two-pass kernels spread one window over dozens of workgroups, so they win whenever the batch
         // cannot fill the GPU with one wave per strip (single-frame tracking: 36 µs vs 144 µs for one
@@ -283,7 +304,7 @@ int ensure_capacity(pdog_tracker *t, int n)
     // worst case strips over all variants so a later pdog_set_variant never reallocates
     int max_strips = 1;
     for (int i = 0; i < kNumVariants; ++i)
-        max_strips = std::max(max_strips, (t->n2 + kVariants[i].tw() - 1) / kVariants[i].tw() + kThinMax);
+        if (!kVariants[i].fused) max_strips = std::max(max_strips, (t->n2 + kVariants[i].tw() - 1) / kVariants[i].tw() + kThinMax);
     max_strips = std::max(max_strips, (t->n2 + 7) / 8);
     if (t->d_part_val) (void)hipFree(t->d_part_val);
     if (t->d_part_idx) (void)hipFree(t->d_part_idx);
@@ -293,6 +314,69 @@ int ensure_capacity(pdog_tracker *t, int n)
     HIP_TRY(hipMalloc(&t->d_part_val, sizeof(float) * (size_t)n * max_strips));
     HIP_TRY(hipMalloc(&t->d_part_idx, sizeof(int) * (size_t)n * max_strips));
     t->cap_windows = n;
+    return PDOG_OK;
+}
+
+// fused-kernel instance (runtime kernel length)
+fused_fn_t fused_kernel_for(int L, bool resp)
+{
+    (void)L;
+    return resp ? (fused_fn_t)dog_fused_kernel<true> : (fused_fn_t)dog_fused_kernel<false>;
+}
+
+// One workgroup per window (chain_len = 1) or per clip (chain_len frames, frame k > 0 starts at frame k−1's answer).
+int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
+                 const int32_t *d_frame_index, const int32_t *d_guesses, int n, int chain_len, int32_t *d_out_ij,
+                 float *d_out_resp, int FH, int FW)
+{
+    FusedGeo fg;
+    LaunchGeo &g = fg.g;
+    std::memset(&g, 0, sizeof g);
+    g.frames = d_frames;
+    g.frame_stride = frame_stride;
+    g.row_stride = row_stride;
+    g.frame_index = d_frame_index;
+    g.guesses = d_guesses;
+    g.resp = d_out_resp;
+    g.fh = FH; g.fw = FW; g.r1 = t->r1; g.r2 = t->r2; g.n1 = t->n1; g.n2 = t->n2;
+    g.L = t->L; g.fill = t->fill; g.nstrips = 1; g.n = n; g.nslots = 1; g.nblocks = n;
+    fg.NA = t->n1 + t->L - 1;
+    fg.TWin = t->n2 + t->L - 1;
+    fg.pitchA = fused_pitch_a(t->n2, t->L);
+    fg.pitchV = fused_pitch_v(t->n1, t->L);
+    fg.cshift = 0;
+    while ((1 << fg.cshift) < (fg.TWin + 3) / 4) ++fg.cshift;
+    // outputs per task: fewest rounds of 1024 tasks, then least work per task (≈ P outputs + 2 of fixed cost)
+    auto pick = [](int lines, int nout, std::initializer_list<int> ps, double fixed) {
+        int best = 0;
+        double best_cost = 0;
+        for (int p : ps) {
+            const long long tasks = (long long)lines * ((nout + p - 1) / p);
+            const double cost = (double)((tasks + FUSED_NT - 1) / FUSED_NT) * (p + fixed);
+            if (!best || cost < best_cost) { best = p; best_cost = cost; }
+        }
+        return best;
+    };
+    fg.pr = pick(fg.NA, t->n2, {3, 4, 5, 6, 8}, 2.0);
+    fg.pc = pick(t->n2, t->n1, {2, 3, 4, 6, 8}, 1.5);
+    if (const char *e = std::getenv("PDOG_FUSED_P")) { // tuning switch: "pr,pc"
+        int a = 0, b = 0;
+        if (std::sscanf(e, "%d,%d", &a, &b) == 2 && (a == 3 || a == 4 || a == 5 || a == 6 || a == 8) &&
+            (b == 2 || b == 3 || b == 4 || b == 6 || b == 8)) { fg.pr = a; fg.pc = b; }
+    }
+    fg.chain_len = chain_len;
+    fg.out_ij = d_out_ij;
+    const size_t lds = fused_lds_bytes(t->n1, t->n2, t->L);
+    typedef fused_fn_t fused_fn;
+    fused_fn fn = fused_kernel_for(t->L, d_out_resp != nullptr);
+#ifdef PDOG_ABLATIONS
+    if (d_out_resp && std::getenv("PDOG_FUSED_DIAG")) { // phase stamps instead of the response (tools/fused_phases.py)
+        fn = (fused_fn)dog_fused_kernel<true, 1>;
+        if (int rc = raise_lds_limit((const void *)fn, lds)) return rc;
+    }
+#endif
+    hipLaunchKernelGGL(fn, dim3(n), dim3(FUSED_NT), lds, t->stream, fg, (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
+    HIP_TRY(hipGetLastError());
     return PDOG_OK;
 }
 
@@ -320,6 +404,10 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     g.nslots = t->nstrips + t->nthin;
     g.thin_x0 = t->thin_x0;
     g.nthin = t->nthin;
+    // windows that fit in LDS, in batches too small to fill the GPU any other way: one workgroup per window, one launch
+    if (v.fused || (!t->forced_variant && t->fused_ok &&
+                    (v.twopass ? n <= 256 : (long long)n * (t->nstrips + (t->nthin ? 1 : 0)) < 1000)))
+        return launch_fused(t, d_frames, frame_stride, row_stride, d_frame_index, d_guesses, n, 1, d_out_ij, d_out_resp, FH, FW);
     // small batches: fewer than ≈1000 strip-waves cannot fill 256 CUs × 8 waves; the two-pass kernels can
     const bool small = !v.twopass && !t->forced_variant && t->small_twopass && (long long)n * (t->nstrips + (t->nthin ? 1 : 0)) < 1000;
     if (v.twopass || small) {
@@ -519,7 +607,8 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
     gaussian_1d(t->sigma, t->L, gp.data());
     gaussian_1d(t->sigma * std::sqrt(2.0), t->L, gm.data());
     const double s = (t->darker ? -1.0 : 1.0) / 255.0; // direction (:42) and N0f8 scale
-    std::vector<f2> tr(t->L), tc(t->L);
+    constexpr int kTapPad = 16; // zero taps past the end: kernels that request taps one block ahead read them
+    std::vector<f2> tr(t->L + kTapPad, f2{0.f, 0.f}), tc(t->L + kTapPad, f2{0.f, 0.f});
     for (int k = 0; k < t->L; ++k) {
         tr[k] = f2{(float)gp[k], (float)gm[k]};
         tc[k] = f2{(float)(s * gp[k]), (float)(-s * gm[k])};
@@ -538,10 +627,10 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
     CREATE_TRY(hipStreamCreateWithFlags(&t->aux_stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
-    CREATE_TRY(hipMalloc(&t->d_taps_row, sizeof(f2) * t->L));
-    CREATE_TRY(hipMalloc(&t->d_taps_col, sizeof(f2) * t->L));
-    CREATE_TRY(hipMemcpy(t->d_taps_row, tr.data(), sizeof(f2) * t->L, hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(t->d_taps_col, tc.data(), sizeof(f2) * t->L, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc(&t->d_taps_row, sizeof(f2) * tr.size()));
+    CREATE_TRY(hipMalloc(&t->d_taps_col, sizeof(f2) * tc.size()));
+    CREATE_TRY(hipMemcpy(t->d_taps_row, tr.data(), sizeof(f2) * tr.size(), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(t->d_taps_col, tc.data(), sizeof(f2) * tc.size(), hipMemcpyHostToDevice));
     {
         // roll_col_body's table: (Tc[t], Tc[t-1]) pairs per parity, T outside 0..l-1 is 0
         const int nqb = roll_col_blocks(t->L);
@@ -583,6 +672,7 @@ int pdog_destroy(pdog_tracker *t)
     if (t->d_small) (void)hipFree(t->d_small);
     if (t->h_pinned) (void)hipHostFree(t->h_pinned);
     if (t->d_resp) (void)hipFree(t->d_resp);
+    if (t->h_tile) (void)hipHostFree(t->h_tile);
     if (t->d_V) (void)hipFree(t->d_V);
     if (t->d_dc) (void)hipFree(t->d_dc);
     if (t->d_chain_tmp) (void)hipFree(t->d_chain_tmp);
@@ -691,8 +781,29 @@ int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride
     if (guess[0] < -hw || guess[0] > t->fh + hw + 1 || guess[1] < -hw || guess[1] > t->fw + hw + 1)
         return fail(PDOG_E_RANGE, "pdog_detect_host: guess outside the padded frame (reference: BoundsError)");
     HIP_TRY(hipSetDevice(t->device));
-    if (!t->d_frame) HIP_TRY(hipMalloc(&t->d_frame, (size_t)t->fh * t->fw));
     if (h_resp && !t->d_resp) HIP_TRY(hipMalloc(&t->d_resp, sizeof(float) * (size_t)t->n1 * t->n2));
+    if (t->var->fused || (t->fused_ok && !t->forced_variant && !std::getenv("PDOG_HOST_COPY"))) {
+        // Latency path: the tile is packed into pinned, device-mapped memory (fill materialised, as in
+        // pdog_detect_batch_host) and the fused kernel reads it in place over PCIe and writes the answer into
+        // the pinned mailbox — one launch and one synchronisation per call, no copy commands.
+        const int th = t->n1 + 2 * hw, tw = t->n2 + 2 * hw, pitch = round_up(tw, 16);
+        if (!t->h_tile) HIP_TRY(hipHostMalloc((void **)&t->h_tile, (size_t)th * pitch, hipHostMallocMapped));
+        uint8_t *d_tile = nullptr;
+        int32_t *d_mail = nullptr;
+        HIP_TRY(hipHostGetDevicePointer((void **)&d_tile, t->h_tile, 0));
+        HIP_TRY(hipHostGetDevicePointer((void **)&d_mail, t->h_pinned, 0));
+        pack_tile(t, h_frame, row_stride, guess[0], guess[1], t->h_tile, pitch);
+        t->h_pinned[0] = t->r1 + hw + 1;   // the guess is the tile's centre
+        t->h_pinned[1] = t->r2 + hw + 1;
+        int rc = launch_fused(t, d_tile, (int64_t)th * pitch, pitch, nullptr, d_mail, 1, 1, d_mail + 2, h_resp ? t->d_resp : nullptr, th, tw);
+        if (rc) return rc;
+        if (h_resp) HIP_TRY(hipMemcpyAsync(h_resp, t->d_resp, sizeof(float) * (size_t)t->n1 * t->n2, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        out_ij[0] = std::min(std::max(guess[0] - t->r1 - hw + t->h_pinned[2] - 1, 1), t->fh);   // tile-local → frame, clamp (:60-61)
+        out_ij[1] = std::min(std::max(guess[1] - t->r2 - hw + t->h_pinned[3] - 1, 1), t->fw);
+        return PDOG_OK;
+    }
+    if (!t->d_frame) HIP_TRY(hipMalloc(&t->d_frame, (size_t)t->fh * t->fw));
     {
         // Only the window's padded tile is read by the kernels (anything else they touch feeds masked
         // lanes), so only that rectangle of the frame crosses PCIe: 109×109 B instead of 2 MB for the
@@ -932,6 +1043,8 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
     // batch that the two-pass kernels spread over many workgroups (21 µs vs 48 µs per frame, one 45×45 window).
     const bool persistent = v.roll && v.chain && chain_strips <= 8 &&
                             (t->forced_variant || !t->small_twopass || (long long)n_clips * chain_strips >= 1000);
+    if (v.fused || (!persistent && !t->forced_variant && t->fused_ok)) // one launch: a workgroup per clip loops over its frames
+        return launch_fused(t, d_frames, frame_stride, row_stride, nullptr, d_start_guesses, n_clips, n_frames, d_out_ij, nullptr, t->fh, t->fw);
     if (persistent) {
         ChainGeo cg;
         LaunchGeo &g = cg.g;

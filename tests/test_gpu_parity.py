@@ -47,22 +47,40 @@ def test_golden_vectors_through_tracker(pt, golden):
         t.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 10, 11, 12, 13, 14, 100, 200])
+@pytest.mark.parametrize("variant", [0, 1, 2, 10, 11, 12, 13, 14, 100, 200, 300])
 def test_every_l65_variant(pt, golden, variant):
+    n_run = 0
     for c in golden:
         if c["l"] != 65:
             continue
         t = pt.Tracker(c["frame"], c["tw"], c["ws"], c["darker"])
-        t.set_variant(variant)
+        try:
+            t.set_variant(variant)
+        except pt.PdogError:
+            assert variant == 300   # the fused kernel needs the whole padded tile in LDS
+            t.close()
+            continue
+        n_run += 1
         assert t.info().variant == variant
         ij, resp = t(c["guess"], want_resp=True)
         assert ij == c["ij"], (c["name"], variant, ij, c["ij"])
         _check_resp(resp, c["resp"], c["name"])
         assert t(c["guess"]) == c["ij"]
         t.close()
+    assert n_run >= 3
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 20, 200])
+def test_golden_via_the_copying_host_path(pt, golden, monkeypatch):
+    """The functor's fallback for windows that do not fit the fused kernel (tile uploaded with copy commands, batch
+    kernels) on the golden cases that normally take the in-place path."""
+    monkeypatch.setenv("PDOG_HOST_COPY", "1")
+    for c in golden:
+        t = pt.Tracker(c["frame"], c["tw"], c["ws"], c["darker"])
+        assert t(c["guess"]) == c["ij"], c["name"]
+        t.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 20, 200, 300])
 def test_other_kernel_lengths(pt, golden, variant):
     for c in golden:
         if c["l"] == 65 or (variant == 20 and c["l"] != 29):
@@ -294,13 +312,19 @@ def test_persistent_multi_clip_chains(pt, oracle):
         d_starts = torch.tensor(starts, dtype=torch.int32).cuda()
         # default: few clips run as small per-frame batches; with the kernel pinned (set_variant) the
         # persistent one-launch chain kernel runs — both must reproduce the oracle's chains
-        for pin in (False, True):
+        for pin in (False, True, 300):
             bt = pt.BatchTracker(h, w, tw, ws, True, fill)
-            if pin:
+            if pin is True:
                 if bt.info().variant < 100 or bt.info().variant >= 200:
                     bt.close()
                     continue      # no roll instance (hence no persistent kernel) for this kernel length
                 bt.set_variant(bt.info().variant)
+            elif pin == 300:
+                try:
+                    bt.set_variant(300)   # fused kernel: one workgroup per clip, the frame loop inside the kernel
+                except pt.PdogError:
+                    bt.close()
+                    continue
             out = bt.detect_chains(d_clips, d_starts)
             bt.sync()
             got = out.cpu().numpy()
@@ -496,3 +520,92 @@ def test_host_batch_ingest_equals_device_batch(pt, oracle, tw, ws, chunk, monkey
     K = oracle.dog_kernel(oracle.sigma(tw), True)
     for b in range(0, n, 37 if tw < 100 else 97):               # and a few against the oracle directly
         assert tuple(got[b]) == oracle.detect(frames[fi[b]], fill, K, radii, g[b])
+
+
+def test_distinct_trackers_from_distinct_threads(pt, oracle):
+    """SURVEY §8b threading: a handle is single-caller, distinct handles are usable from distinct threads
+    (README.md:214 of the reference: concurrent `track` calls).  Four host threads, each with its own
+    Tracker / BatchTracker of a different geometry, call concurrently (ctypes drops the GIL)."""
+    import threading
+    from oracle import synth
+    cases = [(25, (45, 45)), (10, (21, 21)), (25, (96, 64)), (40, (81, 81))]
+    results, errors = {}, []
+
+    def run(k, tw, ws):
+        try:
+            import torch
+            radii = (ws[0] // 2, ws[1] // 2)
+            frames, guesses, _ = synth.make_batch(12, 240, 320, tw, radii, True, seed=50 + k, noise=2)
+            tr = pt.Tracker(frames[0], tw, ws, True)
+            fill = tr.img.fillvalue
+            singles = []
+            for b in range(len(frames)):
+                tr.img.data[...] = frames[b]
+                singles.append(tr((int(guesses[b, 0]), int(guesses[b, 1]))))
+            bt = pt.BatchTracker(240, 320, tw, ws, True, fill)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                out = bt.detect(torch.from_numpy(frames).cuda(), torch.from_numpy(guesses).cuda())
+                torch.cuda.current_stream().synchronize()
+                out = out.cpu().numpy()
+            host = bt.detect_host(frames, guesses)
+            bt.close()
+            results[k] = (frames, guesses, fill, np.array(singles, np.int32), out, host)
+        except Exception as e:                                   # noqa: BLE001 - reported by the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(k, tw, ws)) for k, (tw, ws) in enumerate(cases)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k, (tw, ws) in enumerate(cases):
+        frames, guesses, fill, singles, out, host = results[k]
+        K = oracle.dog_kernel(oracle.sigma(tw), True)
+        exp = oracle.detect_batch(frames, fill, K, (ws[0] // 2, ws[1] // 2), guesses)
+        assert np.array_equal(singles, exp) and np.array_equal(out, exp) and np.array_equal(host, exp)
+
+
+def test_fused_kernel_batches_and_chains(pt, oracle):
+    """dog_fused_kernel (one workgroup per window, tile in LDS, one launch): seeded batches of odd window shapes
+    with the dense response against the oracle, and the in-kernel frame loop against the oracle's chain; both as
+    the automatic choice for small batches and pinned (variant 300)."""
+    import torch
+    from oracle import synth
+    from oracle.dog_oracle import OracleTracker
+    rng = np.random.default_rng(77)
+    for tw, ws, (h, w), n in ((25, (45, 45), (240, 320), 40), (25, (31, 57), (120, 90), 24), (10, (21, 21), (100, 140), 300),
+                              (16, (5, 71), (80, 200), 16), (25, (63, 1), (150, 150), 9), (30, (33, 33), (200, 200), 12)):
+        radii = (ws[0] // 2, ws[1] // 2)
+        frames, guesses, _ = synth.make_batch(n, h, w, tw, radii, True, seed=int(rng.integers(1 << 30)), noise=3)
+        fill = oracle.mode_u8(frames[0])
+        K = oracle.dog_kernel(oracle.sigma(tw), True)
+        exp = oracle.detect_batch(frames, fill, K, radii, guesses)
+        auto = _batch(pt, frames, guesses, tw, ws, True, fill)
+        pinned, resp = _batch(pt, frames, guesses, tw, ws, True, fill, want_resp=True, variant=300)
+        assert np.array_equal(auto, exp) and np.array_equal(pinned, exp), (tw, ws)
+        for b in range(0, n, max(1, n // 5)):
+            _, r = oracle.detect(frames[b], fill, K, radii, guesses[b], want_resp=True)
+            _check_resp(resp[b].T, r, f"fused {ws} {b}")
+    # chains: 5 clips x 30 frames, default 45x45 window; the automatic choice for few clips is the fused kernel
+    h, w, tw, ws, nclips, nf = 160, 220, 25, (45, 45), 5, 30
+    clips, starts, refs = [], [], []
+    for c in range(nclips):
+        pos = np.clip(np.cumsum(rng.integers(-6, 7, (nf, 2)), 0) + np.array([h // 2, w // 2]), 5, [h - 5, w - 5])
+        fr = np.stack([synth.disc_frame(h, w, (int(p[0]), int(p[1])), tw, True) for p in pos])
+        clips.append(np.clip(fr.astype(np.int16) + rng.integers(-3, 4, fr.shape), 0, 255).astype(np.uint8))
+        starts.append((int(pos[0][0]) - 2, int(pos[0][1]) + 5))
+    fill = oracle.mode_u8(clips[0][0])
+    for c in range(nclips):
+        ot = OracleTracker(clips[c][0], tw, ws, True, oracle)
+        ot.fill = fill
+        r = [ot(starts[c])]
+        for f in clips[c][1:]:
+            ot.data[...] = f
+            r.append(ot(r[-1]))
+        refs.append(np.array(r, np.int32))
+    bt = pt.BatchTracker(h, w, tw, ws, True, fill)
+    got = bt.detect_chains(torch.from_numpy(np.stack(clips)).cuda(), torch.tensor(starts, dtype=torch.int32).cuda()).cpu().numpy()
+    single = bt.detect_chain(torch.from_numpy(clips[2]).cuda(), starts[2]).cpu().numpy()
+    bt.close()
+    assert np.array_equal(got, np.stack(refs)) and np.array_equal(single, refs[2])
