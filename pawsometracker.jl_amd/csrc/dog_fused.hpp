@@ -29,6 +29,8 @@ struct FusedGeo {
     int pr, pc;          // outputs per task in the row / column pass, chosen per geometry so that the tasks fill the 1024 threads
     int chain_len;       // 1: n independent windows.  > 1: clip b = frames b·chain_len …, frame k > 0 starts at frame k−1's result
     int32_t *out_ij;     // [n][chain_len][2], clamped to the frame
+    int32_t *done_flag;  // NULL, or a word in host-coherent memory that receives done_value (system-scope release) once
+    int32_t done_value;  // window 0's answer is written: the host functor polls it instead of waiting for the kernel's end
 };
 
 constexpr int FUSED_NT = 1024, FUSED_PMAX = 8, FUSED_U = 8;
@@ -295,6 +297,8 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
                 o[1] = j;
                 s_guess[0] = i;
                 s_guess[1] = j;
+                if (fg.done_flag && b == 0 && k == fg.chain_len - 1)
+                    __hip_atomic_store(fg.done_flag, fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         __syncthreads();

@@ -176,9 +176,12 @@ struct pdog_tracker {
     // host-path staging (pdog_detect_host / chain seed)
     uint8_t *d_frame = nullptr;
     int32_t *d_small = nullptr; // [0..1] guess, [2..3] result
-    int32_t *h_pinned = nullptr; // pinned mirror of d_small: the host path's 8-byte copies skip the pageable staging
+    int32_t *h_pinned = nullptr; // pinned, host-coherent mailbox: [0..1] guess, [2..3] result, [4] completion ticket of the functor
+    int32_t ticket = 0;
     float *d_resp = nullptr;
     uint8_t *h_tile = nullptr;   // pinned, device-mapped: the functor's window tile when the fused kernel reads it in place
+    uint8_t *d_tile_map = nullptr; // device addresses of h_tile and of the h_pinned mailbox
+    int32_t *d_mail_map = nullptr;
     // host-batch ingest (pdog_detect_batch_host): rotating pinned staging / device tile slots
     static constexpr int kIngestSlots = 3;
     uint8_t *h_stage[kIngestSlots] = {nullptr, nullptr, nullptr};
@@ -327,7 +330,7 @@ fused_fn_t fused_kernel_for(int L, bool resp)
 // One workgroup per window (chain_len = 1) or per clip (chain_len frames, frame k > 0 starts at frame k−1's answer).
 int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
                  const int32_t *d_frame_index, const int32_t *d_guesses, int n, int chain_len, int32_t *d_out_ij,
-                 float *d_out_resp, int FH, int FW)
+                 float *d_out_resp, int FH, int FW, int32_t *d_done_flag = nullptr, int32_t done_value = 0)
 {
     FusedGeo fg;
     LaunchGeo &g = fg.g;
@@ -366,6 +369,8 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     }
     fg.chain_len = chain_len;
     fg.out_ij = d_out_ij;
+    fg.done_flag = d_done_flag;
+    fg.done_value = done_value;
     const size_t lds = fused_lds_bytes(t->n1, t->n2, t->L);
     typedef fused_fn_t fused_fn;
     fused_fn fn = fused_kernel_for(t->L, d_out_resp != nullptr);
@@ -650,7 +655,8 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
         CREATE_TRY(hipMemcpy(t->d_taps_roll, tab.data(), sizeof(f2) * tab.size(), hipMemcpyHostToDevice));
     }
     CREATE_TRY(hipMalloc(&t->d_small, sizeof(int32_t) * 4));
-    CREATE_TRY(hipHostMalloc(&t->h_pinned, sizeof(int32_t) * 4, hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(&t->h_pinned, sizeof(int32_t) * 8, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(t->h_pinned, 0, sizeof(int32_t) * 8);
 #undef CREATE_TRY
     rc = ensure_capacity(t, 1);
     if (rc) { pdog_destroy(t); return rc; }
@@ -787,18 +793,44 @@ int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride
         // pdog_detect_batch_host) and the fused kernel reads it in place over PCIe and writes the answer into
         // the pinned mailbox — one launch and one synchronisation per call, no copy commands.
         const int th = t->n1 + 2 * hw, tw = t->n2 + 2 * hw, pitch = round_up(tw, 16);
-        if (!t->h_tile) HIP_TRY(hipHostMalloc((void **)&t->h_tile, (size_t)th * pitch, hipHostMallocMapped));
-        uint8_t *d_tile = nullptr;
-        int32_t *d_mail = nullptr;
-        HIP_TRY(hipHostGetDevicePointer((void **)&d_tile, t->h_tile, 0));
-        HIP_TRY(hipHostGetDevicePointer((void **)&d_mail, t->h_pinned, 0));
+        if (!t->h_tile) {
+            HIP_TRY(hipHostMalloc((void **)&t->h_tile, (size_t)th * pitch, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void **)&t->d_tile_map, t->h_tile, 0));
+            HIP_TRY(hipHostGetDevicePointer((void **)&t->d_mail_map, t->h_pinned, 0));
+        }
+        uint8_t *d_tile = t->d_tile_map;
+        int32_t *d_mail = t->d_mail_map;
+        static const bool trace = std::getenv("PDOG_HOST_TRACE") != nullptr; // diagnostic: where a call's wall time goes
+        const auto t0 = std::chrono::steady_clock::now();
         pack_tile(t, h_frame, row_stride, guess[0], guess[1], t->h_tile, pitch);
         t->h_pinned[0] = t->r1 + hw + 1;   // the guess is the tile's centre
         t->h_pinned[1] = t->r2 + hw + 1;
-        int rc = launch_fused(t, d_tile, (int64_t)th * pitch, pitch, nullptr, d_mail, 1, 1, d_mail + 2, h_resp ? t->d_resp : nullptr, th, tw);
+        const auto t1 = std::chrono::steady_clock::now();
+        // completion: the kernel publishes a ticket right after the answer (system-scope release into the coherent
+        // mailbox) and the host polls for it — the answer is back before the kernel's end-of-grid bookkeeping; the
+        // stream stays ordered for whatever is queued next.  With a response copy, or if the ticket does not show up
+        // in time (a failed launch), the stream is synchronised as usual.
+        const int32_t ticket = ++t->ticket;
+        int rc = launch_fused(t, d_tile, (int64_t)th * pitch, pitch, nullptr, d_mail, 1, 1, d_mail + 2, h_resp ? t->d_resp : nullptr, th, tw,
+                              d_mail + 4, ticket);
         if (rc) return rc;
         if (h_resp) HIP_TRY(hipMemcpyAsync(h_resp, t->d_resp, sizeof(float) * (size_t)t->n1 * t->n2, hipMemcpyDeviceToHost, t->stream));
-        HIP_TRY(hipStreamSynchronize(t->stream));
+        const auto t2 = std::chrono::steady_clock::now();
+        bool done = false;
+        if (!h_resp && !std::getenv("PDOG_HOST_SYNC")) {
+            const auto deadline = t2 + std::chrono::microseconds(500);
+            for (int spin = 0;; ++spin) {
+                if (__atomic_load_n(&t->h_pinned[4], __ATOMIC_ACQUIRE) == ticket) { done = true; break; }
+                if ((spin & 63) == 63 && std::chrono::steady_clock::now() > deadline) break;
+                __builtin_ia32_pause();
+            }
+        }
+        if (!done) HIP_TRY(hipStreamSynchronize(t->stream));
+        if (trace) {
+            const auto t3 = std::chrono::steady_clock::now();
+            auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            std::fprintf(stderr, "pdog functor: pack %.1f us, launch %.1f us, sync %.1f us\n", us(t0, t1), us(t1, t2), us(t2, t3));
+        }
         out_ij[0] = std::min(std::max(guess[0] - t->r1 - hw + t->h_pinned[2] - 1, 1), t->fh);   // tile-local → frame, clamp (:60-61)
         out_ij[1] = std::min(std::max(guess[1] - t->r2 - hw + t->h_pinned[3] - 1, 1), t->fw);
         return PDOG_OK;

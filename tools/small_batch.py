@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Kernel time vs batch size for the roll and two-pass paths (which one fills the GPU at small n)."""
+"""Kernel time vs batch size: roll kernel (one wave per strip, v100), two-pass (many workgroups per window, v200),
+fused (one workgroup per window, one launch, v300 — windows whose padded tile fits in LDS)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,9 +12,13 @@ for (ws, label) in (((256, 256), "257x257"), ((270, 480), "271x481"), ((45, 45),
         frames, gh, _ = make_frames(torch, n, 1080, 1920, 25, (ws[0] // 2, ws[1] // 2), 0, 3, dev)
         g = torch.from_numpy(gh).cuda()
         row = [f"{label} n={n:5d}"]
-        for variant in (100, 200):
+        for variant in (100, 200, 300):
             bt = pt.BatchTracker(1080, 1920, 25, ws, True, 128)
-            bt.set_variant(variant); bt.use_torch_stream(); bt.reserve(n)
+            try:
+                bt.set_variant(variant)
+            except pt.PdogError:      # 300 = fused one-workgroup kernel: needs the window's padded tile in LDS
+                bt.close(); continue
+            bt.use_torch_stream(); bt.reserve(n)
             out = torch.empty((n, 2), dtype=torch.int32, device=dev)
             for _ in range(3): bt.detect(frames, g, out=out)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
