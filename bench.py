@@ -156,11 +156,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PDOG_BENCH_BACKEND=gloo rehearses the N > 1 control flow where RCCL cannot run (several ranks on ONE GPU of a
+    # development box): ranks then share devices round-robin and the gather goes through host memory
+    backend = os.environ.get("PDOG_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     fh, fw, tw, ws, batch, desc = WORKLOADS[args.workload]
     if args.batch:
@@ -173,7 +180,7 @@ def main():
     if args.noise:
         fill = pt.mode(frames[0].cpu().numpy())                 # mode of the first frame, :47
     guesses = torch.from_numpy(guesses_h).to(dev)
-    bt = pt.BatchTracker(fh, fw, tw, ws, True, fill, device=local_rank)
+    bt = pt.BatchTracker(fh, fw, tw, ws, True, fill, device=dev_index)
     if args.variant >= 0:
         bt.set_variant(args.variant)
     bt.reserve(batch)
@@ -190,6 +197,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if world > 1:
+        pt.gather_positions(out, n_total)   # RCCL sets up its point-to-point channels on first use: not part of any timed step
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
     if world > 1:
@@ -209,7 +218,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # HIP events on the launch stream
@@ -238,7 +247,8 @@ def main():
             "config": {"workload": f"{args.workload}: {desc}", "frame": [fh, fw], "window": [info.win_h, info.win_w],
                        "batch_per_gpu": batch, "target_width": tw, "kernel_len": info.kernel_len,
                        "noise_levels": args.noise, "variant": info.variant, "strips": info.n_strips,
-                       "sharding": f"frames x{world}, gather int32[n,2] to rank 0" if world > 1 else "single GPU"},
+                       "sharding": (f"frames x{world}, gather int32[n,2] to rank 0" + ("" if backend == "nccl" else f" ({backend} rehearsal)"))
+                                   if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": stored_traffic(args.workload, info.variant, batch),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_window": abytes,

@@ -173,6 +173,8 @@ def gather_positions(local_ij, n_total, group=None, dst=0, async_op=False):
     rank = dist.get_rank(group)
     sizes = [shard_range(n_total, r, world) for r in range(world)]
     max_n = max(hi - lo for lo, hi in sizes)
+    if local_ij.is_cuda and dist.get_backend(group) == "gloo":
+        local_ij = local_ij.cpu()      # gloo has no device-memory gather: rehearsals and CPU tests go through host memory
     pad = torch.zeros((max_n, 2), dtype=torch.int32, device=local_ij.device)
     pad[: local_ij.shape[0]] = local_ij
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
