@@ -609,3 +609,52 @@ def test_fused_kernel_batches_and_chains(pt, oracle):
     single = bt.detect_chain(torch.from_numpy(clips[2]).cuda(), starts[2]).cpu().numpy()
     bt.close()
     assert np.array_equal(got, np.stack(refs)) and np.array_equal(single, refs[2])
+
+
+def test_identical_targets_tie_goes_to_the_first_in_column_major_order(pt, oracle):
+    """findmax (:59) returns the FIRST maximum in column-major order.  Several identical discs in one noise-free
+    window give bit-identical responses at their centres only if every output sees its taps in the same order,
+    whatever strip, sub-chunk, remainder column or workgroup computes it: the answer must be the disc with the
+    smallest column (then row), for every kernel family, and equal to the oracle's."""
+    from oracle import synth
+    fh, fw = 400, 720
+
+    def frame_with(discs, tw, darker=True):
+        f = np.full((fh, fw), 128, np.uint8)
+        rad = tw // 2
+        yy, xx = np.mgrid[-rad:rad + 1, -rad:rad + 1]
+        m = (yy * yy + xx * xx) <= rad * rad
+        for (i, j) in discs:
+            f[i - 1 - rad:i + rad, j - 1 - rad:j + rad][m] = 0 if darker else 255
+        return f
+
+    # window 181 x 451 centred at (200, 360): columns 135..585 -> 7 strips of 64 + 3 remainder columns (583..585)
+    tw, ws, guess = 25, (181, 451), (200, 360)
+    layouts = [[(250, 200), (150, 500), (200, 350)],            # different strips and row chunks; first = column 200
+               [(150, 500), (260, 500), (130, 560)],            # same column twice: smaller row wins
+               [(200, 584), (200, 300)],                        # one centre in the remainder columns (thin kernel)
+               [(280, 170), (120, 170 + 64), (200, 170 + 128)]]  # same lane of three consecutive strips
+    K = oracle.dog_kernel(oracle.sigma(tw), True)
+    for discs in layouts:
+        f = frame_with(discs, tw)
+        exp = min(discs, key=lambda d: (d[1], d[0]))
+        assert oracle.detect(f, 128, K, (ws[0] // 2, ws[1] // 2), guess) == exp
+        for variant in (None, 100, 200, 2, 10):
+            got = _batch(pt, f[None], np.array([guess], np.int32), tw, ws, True, 128, variant=variant)
+            assert tuple(int(v) for v in got[0]) == exp, (discs, variant)
+        # enough copies of the window to take the batch kernels' large-batch path as well
+        got = _batch(pt, f[None], np.tile(np.array([guess], np.int32), (300, 1)), tw, ws, True, 128, frame_index=np.zeros(300, np.int32))
+        assert (got == np.array(exp)).all()
+    # a window that fits the fused kernel: two small bright discs (tw 6 -> l = 17)
+    tw, ws, guess = 6, (45, 45), (100, 100)
+    for discs in ([(90, 110), (108, 92)], [(95, 95), (95, 108)], [(112, 100), (88, 100)]):
+        f = frame_with(discs, tw, darker=False)
+        exp = min(discs, key=lambda d: (d[1], d[0]))
+        K6 = oracle.dog_kernel(oracle.sigma(tw), False)
+        assert oracle.detect(f, 128, K6, (22, 22), guess) == exp
+        for variant in (None, 300, 200, 117):
+            got = _batch(pt, f[None], np.array([guess], np.int32), tw, ws, False, 128, variant=variant)
+            assert tuple(int(v) for v in got[0]) == exp, (discs, variant)
+        tr = pt.Tracker(f, tw, ws, False)
+        assert tr(guess) == exp
+        tr.close()
