@@ -36,6 +36,9 @@ struct TwoPassGeo {
     int hblocks_per_win;    // column-pass workgroups per window = ceil(n2 / 16)
     int pitchA;             // LDS row pitch of the row pass, in floats
     int pitchV;             // LDS row pitch of the column pass, in f2
+    // low-latency variants (small batches): no separate DC and strip-combine launches
+    int *__restrict__ counter;   // [n] zero between launches: column-pass workgroups that have delivered their partial
+    int32_t *__restrict__ out_ij; // [n][2] final positions, written by the last column-pass workgroup of a window
 };
 
 __global__ __launch_bounds__(64) void dog_dc_kernel(const LaunchGeo g, int *__restrict__ dc)
@@ -52,7 +55,9 @@ __global__ __launch_bounds__(64) void dog_dc_kernel(const LaunchGeo g, int *__re
 
 // ---- row pass (u8 rows → RT) ----
 constexpr int HP_ROWS = 16; // rows per workgroup in both passes
-template <int P, int U>
+// DCIN: the workgroup derives the window's DC level itself (the same 1024 integer samples, 4 per thread) instead of
+// reading the result of dog_dc_kernel: one launch less where launches are what a small batch costs.
+template <int P, int U, bool DCIN = false>
 __global__ __launch_bounds__(256) void dog_h1_kernel(const TwoPassGeo tg, const f2 *__restrict__ taps_row)
 {
     const LaunchGeo &g = tg.g;
@@ -69,7 +74,21 @@ __global__ __launch_bounds__(256) void dog_h1_kernel(const TwoPassGeo tg, const 
     const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
     const int ti0 = g.guesses[2 * b] - g.r1 - 1 - hw;
     const int wj0 = g.guesses[2 * b + 1] - g.r2 - 1 - hw;
-    const int dc = tg.dc[b];
+    int dc;
+    if (DCIN) {
+        __shared__ int s_dcsum[NW];
+        int sum = dc_sample_sum(g, frame, ti0, wj0, L, tid, NT);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        if (lane == 0) s_dcsum[wave] = sum;
+        __syncthreads();
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) total += s_dcsum[w];
+        dc = dc_from_sum(total, g.fill);
+    } else {
+        dc = tg.dc[b];
+    }
     // stage 16 tile rows as f32 (pixel − dc); outside the frame = fill − dc
     for (int r = wave; r < HP_ROWS; r += NW) {
         const int a = a0 + r, gi = ti0 + a;
@@ -144,7 +163,10 @@ __global__ __launch_bounds__(256) void dog_h1_kernel(const TwoPassGeo tg, const 
 }
 
 // ---- column pass + peak (on RT) ----
-template <int P, int U, bool RESP, int HR = HP_ROWS>
+// FIN: the workgroup that delivers a window's last partial also combines them, maps the index and clamps
+// (dog_finalize_kernel's job, :60-61) — no separate launch.  Partials cross workgroups through L2: release fence +
+// device-scope counter on the writer side, device-scope loads on the reader side; the counter is left at zero.
+template <int P, int U, bool RESP, int HR = HP_ROWS, bool FIN = false>
 __global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, const f2 *__restrict__ taps_col)
 {
     const LaunchGeo &g = tg.g;
@@ -233,11 +255,43 @@ __global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, con
     }
     if (lane == 0) { sval[wave] = best; sidx[wave] = best_idx; }
     __syncthreads();
+    __shared__ int s_last;
     if (tid == 0) {
         for (int w = 1; w < NW; ++w)
             if (sval[w] > best || (sval[w] == best && sidx[w] < best_idx)) { best = sval[w]; best_idx = sidx[w]; }
-        g.part_val[b * g.nslots + rb] = best;
-        g.part_idx[b * g.nslots + rb] = best_idx;
+        if (FIN) {
+            __hip_atomic_store(&g.part_val[b * g.nslots + rb], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&g.part_idx[b * g.nslots + rb], best_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int old = __hip_atomic_fetch_add(&tg.counter[b], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old == tg.hblocks_per_win - 1);
+        } else {
+            g.part_val[b * g.nslots + rb] = best;
+            g.part_idx[b * g.nslots + rb] = best_idx;
+        }
+    }
+    if (FIN) {
+        __syncthreads();
+        if (s_last && wave == 0) {
+            float bv = -__builtin_huge_valf();
+            int bi = 0x7fffffff;
+            for (int sl = lane; sl < g.nslots; sl += 64) {
+                const float v = __hip_atomic_load(&g.part_val[b * g.nslots + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int i = __hip_atomic_load(&g.part_idx[b * g.nslots + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ov = __shfl_down(bv, off, 64);
+                const int oi = __shfl_down(bi, off, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (lane == 0) {
+                const int x = bi / g.n1, y = bi - x * g.n1;
+                tg.out_ij[2 * b] = min(max(g.guesses[2 * b] - g.r1 + y, 1), g.fh);       // :60-61
+                tg.out_ij[2 * b + 1] = min(max(g.guesses[2 * b + 1] - g.r2 + x, 1), g.fw);
+                __hip_atomic_store(&tg.counter[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 

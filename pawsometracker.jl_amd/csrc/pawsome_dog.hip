@@ -163,6 +163,7 @@ struct pdog_tracker {
     size_t v_bytes = 0;
     int *d_dc = nullptr;
     int dc_cap = 0;
+    int *d_counter = nullptr;  // [kLowLatMax] zero between launches: delivered column-pass partials per window (low-latency two-pass)
     hipStream_t own_stream = nullptr, stream = nullptr;
     // side stream + fork/join events: the thin-remainder kernel runs beside the strips (its waves fit in
     // the registers the 2-waves-per-SIMD roll kernel leaves free) instead of after them
@@ -262,10 +263,13 @@ int choose_variant(pdog_tracker *t, int forced)
                 if (int rc = raise_lds_limit(f, hl)) return rc;
             }
             const size_t hl8 = (size_t)8 * twopass_pitch(t->n1, t->L, 8) * sizeof(f2);
-            for (const void *f : {(const void *)dog_hpass_kernel<7, 16, false, 8>, (const void *)dog_hpass_kernel<7, 16, true, 8>}) {
+            for (const void *f : {(const void *)dog_hpass_kernel<7, 16, false, 8>, (const void *)dog_hpass_kernel<7, 16, true, 8>,
+                                  (const void *)dog_hpass_kernel<7, 16, false, 8, true>, (const void *)dog_hpass_kernel<7, 16, true, 8, true>}) {
                 if (int rc = raise_lds_limit(f, hl8)) return rc;
             }
-            if (int rc = raise_lds_limit((const void *)dog_h1_kernel<13, 8>, h1l)) return rc;
+            for (const void *f : {(const void *)dog_h1_kernel<13, 8>, (const void *)dog_h1_kernel<13, 8, true>}) {
+                if (int rc = raise_lds_limit(f, h1l)) return rc;
+            }
             t->small_twopass = true;
         }
     }
@@ -276,10 +280,13 @@ int choose_variant(pdog_tracker *t, int forced)
         for (const void *f : {(const void *)dog_hpass_kernel<13, 16, false>, (const void *)dog_hpass_kernel<13, 16, true>}) {
             if (int rc = raise_lds_limit(f, (size_t)hl)) return rc;
         }
-        for (const void *f : {(const void *)dog_hpass_kernel<7, 16, false, 8>, (const void *)dog_hpass_kernel<7, 16, true, 8>}) {
+        for (const void *f : {(const void *)dog_hpass_kernel<7, 16, false, 8>, (const void *)dog_hpass_kernel<7, 16, true, 8>,
+                              (const void *)dog_hpass_kernel<7, 16, false, 8, true>, (const void *)dog_hpass_kernel<7, 16, true, 8, true>}) {
             if (int rc = raise_lds_limit(f, (size_t)8 * twopass_pitch(t->n1, t->L, 8) * sizeof(f2))) return rc;
         }
-        if (int rc = raise_lds_limit((const void *)dog_h1_kernel<13, 8>, (size_t)h1l)) return rc;
+        for (const void *f : {(const void *)dog_h1_kernel<13, 8>, (const void *)dog_h1_kernel<13, 8, true>}) {
+            if (int rc = raise_lds_limit(f, (size_t)h1l)) return rc;
+        }
         return PDOG_OK;
     }
     if (best->roll && best->thin && t->n2 > best->tw()) {
@@ -450,10 +457,32 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         }
         tg.RT = t->d_V;
         tg.dc = t->d_dc;
-        hipLaunchKernelGGL(dog_dc_kernel, dim3(n), dim3(64), 0, t->stream, g, t->d_dc);
-        HIP_TRY(hipGetLastError());
+        tg.counter = nullptr;
+        tg.out_ij = d_out_ij;
         const size_t l1 = (size_t)HP_ROWS * tg.pitchA * sizeof(float);
         const size_t l2 = (size_t)hr * tg.pitchV * sizeof(f2);
+        // A handful of windows (single-clip chains and functor calls with windows too large for the fused kernel,
+        // the auto-detect pass): launches are what such a batch costs, so the DC level is derived inside the row pass
+        // and the last column-pass workgroup of a window combines its partials — two launches instead of four.
+        constexpr int kLowLatMax = 16; // measured crossover (257×257 and 271×481 windows): 2 launches win up to 16 windows, 4 launches beyond
+        if (n <= kLowLatMax && n <= chunk && hr == 8 && !std::getenv("PDOG_TWOPASS_4L")) {
+            if (!t->d_counter) {
+                HIP_TRY(hipMalloc(&t->d_counter, sizeof(int) * kLowLatMax));
+                HIP_TRY(hipMemsetAsync(t->d_counter, 0, sizeof(int) * kLowLatMax, t->stream));
+            }
+            tg.counter = t->d_counter;
+            tg.win0 = 0;
+            hipLaunchKernelGGL((dog_h1_kernel<13, 8, true>), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
+            HIP_TRY(hipGetLastError());
+            if (d_out_resp)
+                hipLaunchKernelGGL((dog_hpass_kernel<7, 16, true, 8, true>), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
+            else
+                hipLaunchKernelGGL((dog_hpass_kernel<7, 16, false, 8, true>), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
+            HIP_TRY(hipGetLastError());
+            return PDOG_OK;
+        }
+        hipLaunchKernelGGL(dog_dc_kernel, dim3(n), dim3(64), 0, t->stream, g, t->d_dc);
+        HIP_TRY(hipGetLastError());
         for (int w0 = 0; w0 < n; w0 += chunk) {
             const int nw = std::min(chunk, n - w0);
             tg.win0 = w0;
@@ -681,6 +710,7 @@ int pdog_destroy(pdog_tracker *t)
     if (t->h_tile) (void)hipHostFree(t->h_tile);
     if (t->d_V) (void)hipFree(t->d_V);
     if (t->d_dc) (void)hipFree(t->d_dc);
+    if (t->d_counter) (void)hipFree(t->d_counter);
     if (t->d_chain_tmp) (void)hipFree(t->d_chain_tmp);
     if (t->h2d_stream) { (void)hipStreamSynchronize(t->h2d_stream); (void)hipStreamDestroy(t->h2d_stream); }
     for (int k = 0; k < pdog_tracker::kIngestSlots; ++k) {

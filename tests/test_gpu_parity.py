@@ -391,6 +391,24 @@ def test_two_pass_scratch_chunking(pt, oracle, monkeypatch):
     assert np.array_equal(_batch(pt, frames, guesses, tw, ws, True, fill), ref)
     monkeypatch.delenv("PDOG_SCRATCH_MB")
     assert np.array_equal(_batch(pt, frames, guesses, tw, ws, True, fill), ref)
+    # up to 16 windows the two-pass path runs as two launches (DC level inside the row pass, strip combine by the last
+    # column-pass workgroup); PDOG_TWOPASS_4L forces the four-launch form on the same windows.  Twice per tracker:
+    # the per-window counters must be back at zero after a launch.
+    import torch
+    for n in (1, 5, 16, 17):
+        for four in (False, True):
+            if four:
+                monkeypatch.setenv("PDOG_TWOPASS_4L", "1")
+            else:
+                monkeypatch.delenv("PDOG_TWOPASS_4L", raising=False)
+            bt = pt.BatchTracker(160, 200, tw, ws, True, fill)
+            d_f, d_g = torch.from_numpy(frames[:n]).cuda(), torch.from_numpy(guesses[:n]).cuda()
+            for _ in range(2):
+                got, resp = bt.detect(d_f, d_g, want_resp=True)
+                assert np.array_equal(got.cpu().numpy(), ref[:n]), (n, four)
+            _, r0 = oracle.detect(frames[0], fill, K, radii, guesses[0], want_resp=True)
+            _check_resp(resp[0].cpu().numpy().T, r0, f"two-pass n={n} four={four}")
+            bt.close()
 
 
 def test_trackers_with_different_geometry_coexist(pt, oracle):
