@@ -39,6 +39,8 @@ struct TwoPassGeo {
     // low-latency variants (small batches): no separate DC and strip-combine launches
     int *__restrict__ counter;   // [n] zero between launches: column-pass workgroups that have delivered their partial
     int32_t *__restrict__ out_ij; // [n][2] final positions, written by the last column-pass workgroup of a window
+    int32_t *done_flag;          // NULL, or a word in host-coherent memory that receives done_value (system-scope release)
+    int32_t done_value;          // right after window 0's answer: the host functor polls it (see dog_fused.hpp)
 };
 
 __global__ __launch_bounds__(64) void dog_dc_kernel(const LaunchGeo g, int *__restrict__ dc)
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, con
                 tg.out_ij[2 * b] = min(max(g.guesses[2 * b] - g.r1 + y, 1), g.fh);       // :60-61
                 tg.out_ij[2 * b + 1] = min(max(g.guesses[2 * b + 1] - g.r2 + x, 1), g.fw);
                 __hip_atomic_store(&tg.counter[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tg.done_flag && b == 0) __hip_atomic_store(tg.done_flag, tg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }

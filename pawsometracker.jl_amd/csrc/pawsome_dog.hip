@@ -394,9 +394,11 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
 
 int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
                   const int32_t *d_frame_index, const int32_t *d_guesses, int n, int32_t *d_out_ij,
-                  float *d_out_resp, int fh_override = 0, int fw_override = 0)
+                  float *d_out_resp, int fh_override = 0, int fw_override = 0, int32_t *d_done_flag = nullptr,
+                  int32_t done_value = 0, bool *ticket_armed = nullptr)
 {
     const Variant &v = *t->var;
+    if (ticket_armed) *ticket_armed = false; // set where the kernels that run will publish done_value (single-window paths)
     // frames of another size than the tracker's (the packed window tiles of pdog_detect_batch_host)
     const int FH = fh_override ? fh_override : t->fh, FW = fw_override ? fw_override : t->fw;
     LaunchGeo g;
@@ -419,7 +421,11 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     // windows that fit in LDS, in batches too small to fill the GPU any other way: one workgroup per window, one launch
     if (v.fused || (!t->forced_variant && t->fused_ok &&
                     (v.twopass ? n <= 256 : (long long)n * (t->nstrips + (t->nthin ? 1 : 0)) < 1000)))
-        return launch_fused(t, d_frames, frame_stride, row_stride, d_frame_index, d_guesses, n, 1, d_out_ij, d_out_resp, FH, FW);
+    {
+        if (ticket_armed) *ticket_armed = d_done_flag != nullptr;
+        return launch_fused(t, d_frames, frame_stride, row_stride, d_frame_index, d_guesses, n, 1, d_out_ij, d_out_resp, FH, FW,
+                            d_done_flag, done_value);
+    }
     // small batches: fewer than ≈1000 strip-waves cannot fill 256 CUs × 8 waves; the two-pass kernels can
     const bool small = !v.twopass && !t->forced_variant && t->small_twopass && (long long)n * (t->nstrips + (t->nthin ? 1 : 0)) < 1000;
     if (v.twopass || small) {
@@ -459,6 +465,8 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         tg.dc = t->d_dc;
         tg.counter = nullptr;
         tg.out_ij = d_out_ij;
+        tg.done_flag = nullptr;
+        tg.done_value = 0;
         const size_t l1 = (size_t)HP_ROWS * tg.pitchA * sizeof(float);
         const size_t l2 = (size_t)hr * tg.pitchV * sizeof(f2);
         // A handful of windows (single-clip chains and functor calls with windows too large for the fused kernel,
@@ -472,6 +480,9 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
             }
             tg.counter = t->d_counter;
             tg.win0 = 0;
+            tg.done_flag = d_done_flag;
+            tg.done_value = done_value;
+            if (ticket_armed) *ticket_armed = d_done_flag != nullptr;
             hipLaunchKernelGGL((dog_h1_kernel<13, 8, true>), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
             HIP_TRY(hipGetLastError());
             if (d_out_resp)
@@ -818,10 +829,15 @@ int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride
         return fail(PDOG_E_RANGE, "pdog_detect_host: guess outside the padded frame (reference: BoundsError)");
     HIP_TRY(hipSetDevice(t->device));
     if (h_resp && !t->d_resp) HIP_TRY(hipMalloc(&t->d_resp, sizeof(float) * (size_t)t->n1 * t->n2));
-    if (t->var->fused || (t->fused_ok && !t->forced_variant && !std::getenv("PDOG_HOST_COPY"))) {
+    if (!std::getenv("PDOG_HOST_COPY")) {
         // Latency path: the tile is packed into pinned, device-mapped memory (fill materialised, as in
-        // pdog_detect_batch_host) and the fused kernel reads it in place over PCIe and writes the answer into
-        // the pinned mailbox — one launch and one synchronisation per call, no copy commands.
+        // pdog_detect_batch_host) and the kernels read it in place over PCIe — no copy commands.  On the device the
+        // tile is a frame of its own with the guess at its centre; the tile-local answer is mapped back and clamped
+        // (:60-61) here.  Completion: the single-window kernels (fused, two-launch two-pass) publish a ticket right
+        // after the answer (system-scope release into the host-coherent mailbox) and the host polls for it — the
+        // answer is back before the kernel's end-of-grid bookkeeping, and the stream stays ordered for whatever is
+        // queued next.  With a response copy, a pinned batch kernel that publishes no ticket, or a ticket that does
+        // not show up in time (a failed launch), the stream is synchronised as usual.
         const int th = t->n1 + 2 * hw, tw = t->n2 + 2 * hw, pitch = round_up(tw, 16);
         if (!t->h_tile) {
             HIP_TRY(hipHostMalloc((void **)&t->h_tile, (size_t)th * pitch, hipHostMallocMapped));
@@ -836,18 +852,18 @@ int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride
         t->h_pinned[0] = t->r1 + hw + 1;   // the guess is the tile's centre
         t->h_pinned[1] = t->r2 + hw + 1;
         const auto t1 = std::chrono::steady_clock::now();
-        // completion: the kernel publishes a ticket right after the answer (system-scope release into the coherent
-        // mailbox) and the host polls for it — the answer is back before the kernel's end-of-grid bookkeeping; the
-        // stream stays ordered for whatever is queued next.  With a response copy, or if the ticket does not show up
-        // in time (a failed launch), the stream is synchronised as usual.
+        if (t->cap_windows < 1) {
+            if (int rc = ensure_capacity(t, 1)) return rc;
+        }
         const int32_t ticket = ++t->ticket;
-        int rc = launch_fused(t, d_tile, (int64_t)th * pitch, pitch, nullptr, d_mail, 1, 1, d_mail + 2, h_resp ? t->d_resp : nullptr, th, tw,
-                              d_mail + 4, ticket);
+        bool armed = false;
+        int rc = launch_detect(t, d_tile, (int64_t)th * pitch, pitch, nullptr, d_mail, 1, d_mail + 2, h_resp ? t->d_resp : nullptr, th, tw,
+                               d_mail + 4, ticket, &armed);
         if (rc) return rc;
         if (h_resp) HIP_TRY(hipMemcpyAsync(h_resp, t->d_resp, sizeof(float) * (size_t)t->n1 * t->n2, hipMemcpyDeviceToHost, t->stream));
         const auto t2 = std::chrono::steady_clock::now();
         bool done = false;
-        if (!h_resp && !std::getenv("PDOG_HOST_SYNC")) {
+        if (armed && !h_resp && !std::getenv("PDOG_HOST_SYNC")) {
             const auto deadline = t2 + std::chrono::microseconds(500);
             for (int spin = 0;; ++spin) {
                 if (__atomic_load_n(&t->h_pinned[4], __ATOMIC_ACQUIRE) == ticket) { done = true; break; }
