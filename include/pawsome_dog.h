@@ -124,6 +124,15 @@ int pdog_detect_batch(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_st
 int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride,
                      const int32_t guess[2], int32_t out_ij[2], float *h_resp);
 
+/* Host-only helper (no GPU): the padded tile the functor reads for one window — rows
+ * guess[0] - win_h÷2 - l÷2 … guess[0] + win_h÷2 + l÷2 of the frame, likewise columns, (2·(win÷2) + l) per side —
+ * with the PaddedView fill (src/PawsomeTracker.jl:48) materialised wherever it leaves the frame.  This is what
+ * pdog_detect_host / pdog_detect_batch_host hand to the kernels.  Bytes past the tile width up to out_pitch
+ * are set to fill. */
+int pdog_window_tile(const uint8_t *h_frame, int frame_h, int frame_w, int64_t row_stride, int fill,
+                     double target_width, int win_h, int win_w, const int32_t guess[2],
+                     uint8_t *h_out, int64_t out_pitch);
+
 /* n independent applications on frames in HOST memory — the batch form of the ingest step
  * `read!(vid, trckr.img.data)` (src/PawsomeTracker.jl:166) followed by the functor (:55-62).
  * All pointers are HOST pointers (pageable is fine); arguments as pdog_detect_batch.  Only each

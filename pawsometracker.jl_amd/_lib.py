@@ -17,7 +17,7 @@ SYMBOLS = (
     "pdog_abi_version", "pdog_last_error", "pdog_sigma", "pdog_default_window", "pdog_kernel_len",
     "pdog_gaussian_taps", "pdog_mode_u8", "pdog_mode_u8_device", "pdog_create", "pdog_destroy", "pdog_get_info",
     "pdog_set_fill", "pdog_set_stream", "pdog_reserve", "pdog_set_variant", "pdog_sync",
-    "pdog_detect_batch", "pdog_detect_host", "pdog_detect_batch_host", "pdog_detect_chain", "pdog_detect_chains",
+    "pdog_detect_batch", "pdog_detect_host", "pdog_window_tile", "pdog_detect_batch_host", "pdog_detect_chain", "pdog_detect_chains",
 )
 
 
@@ -74,6 +74,8 @@ def lib():
     L.pdog_detect_batch.argtypes = [p, p, i64, i64, i, p, p, i, p, p]
     L.pdog_detect_host.restype = i; L.pdog_detect_host.argtypes = [p, p, i64, p, p, p]
     L.pdog_detect_chain.restype = i; L.pdog_detect_chain.argtypes = [p, p, i64, i64, i, p, p]
+    if hasattr(L, "pdog_window_tile"):
+        L.pdog_window_tile.restype = i; L.pdog_window_tile.argtypes = [p, i, i, i64, i, d, i, i, p, p, i64]
     if hasattr(L, "pdog_detect_batch_host"):
         L.pdog_detect_batch_host.restype = i; L.pdog_detect_batch_host.argtypes = [p, p, i64, i64, i, p, p, i, p]
     if hasattr(L, "pdog_detect_chains"):  # absent only in older A/B builds selected through PAWSOME_DOG_LIB

@@ -913,21 +913,44 @@ namespace {
 // One window's padded tile, (n1+l-1) rows of `pitch` bytes: the frame rectangle the functor reads, with the
 // PaddedView fill (:48) materialised wherever the rectangle leaves the frame.  Tile row a, column b is the
 // padded frame at 1-based (g1 - r1 - l÷2 + a, g2 - r2 - l÷2 + b).
-void pack_tile(const pdog_tracker *t, const uint8_t *frame, int64_t row_stride, int g1, int g2, uint8_t *dst, int pitch)
+void pack_tile_geo(const uint8_t *frame, int fh, int fw, int64_t row_stride, int fill, int L, int r1, int r2, int g1, int g2,
+                   uint8_t *dst, int64_t pitch)
 {
-    const int hw = t->L >> 1, th = t->n1 + 2 * hw, tw = t->n2 + 2 * hw;
-    const int i0 = g1 - t->r1 - hw - 1, j0 = g2 - t->r2 - hw - 1;   // 0-based frame coordinates of tile (0, 0)
+    const int hw = L >> 1, th = 2 * r1 + 1 + 2 * hw, tw = 2 * r2 + 1 + 2 * hw;
+    const int i0 = g1 - r1 - hw - 1, j0 = g2 - r2 - hw - 1;        // 0-based frame coordinates of tile (0, 0)
     const int jl = std::min(tw, std::max(0, -j0));                 // columns left of the frame
-    const int jr = std::max(jl, std::min(tw, t->fw - j0));         // first column right of the frame
+    const int jr = std::max(jl, std::min(tw, fw - j0));            // first column right of the frame
     for (int a = 0; a < th; ++a) {
         uint8_t *row = dst + (size_t)a * pitch;
         const int gi = i0 + a;
-        if (gi < 0 || gi >= t->fh) { std::memset(row, t->fill, (size_t)pitch); continue; }
-        if (jl) std::memset(row, t->fill, (size_t)jl);
+        if (gi < 0 || gi >= fh) { std::memset(row, fill, (size_t)pitch); continue; }
+        if (jl) std::memset(row, fill, (size_t)jl);
         if (jr > jl) std::memcpy(row + jl, frame + (size_t)gi * row_stride + (j0 + jl), (size_t)(jr - jl));
-        if (pitch > jr) std::memset(row + jr, t->fill, (size_t)(pitch - jr));
+        if (pitch > jr) std::memset(row + jr, fill, (size_t)(pitch - jr));
     }
 }
+
+void pack_tile(const pdog_tracker *t, const uint8_t *frame, int64_t row_stride, int g1, int g2, uint8_t *dst, int pitch)
+{
+    pack_tile_geo(frame, t->fh, t->fw, row_stride, t->fill, t->L, t->r1, t->r2, g1, g2, dst, pitch);
+}
+
+} // namespace
+
+// The tile packer as a host-only entry (no GPU): what the host paths hand to the kernels, checkable on a CPU box.
+extern "C" int pdog_window_tile(const uint8_t *h_frame, int frame_h, int frame_w, int64_t row_stride, int fill, double target_width,
+                                int win_h, int win_w, const int32_t guess[2], uint8_t *h_out, int64_t out_pitch)
+{
+    if (!h_frame || !guess || !h_out) return fail(PDOG_E_ARG, "pdog_window_tile: null pointer");
+    if (frame_h <= 0 || frame_w <= 0 || row_stride < frame_w || fill < 0 || fill > 255 || win_h <= 0 || win_w <= 0 || !(target_width > 0))
+        return fail(PDOG_E_ARG, "pdog_window_tile: bad argument");
+    const int L = kernel_len_of_sigma(sigma_of(target_width)), r1 = win_h / 2, r2 = win_w / 2;
+    if (out_pitch < 2 * r2 + L) return fail(PDOG_E_ARG, "pdog_window_tile: out_pitch smaller than the tile width");
+    pack_tile_geo(h_frame, frame_h, frame_w, row_stride, fill, L, r1, r2, guess[0], guess[1], h_out, out_pitch);
+    return PDOG_OK;
+}
+
+namespace {
 
 int ingest_threads()
 {

@@ -73,3 +73,33 @@ def test_create_fails_loudly_without_gpu():
     with pytest.raises(pt.PdogError) as e:
         pt.Tracker(np.full((32, 32), 128, np.uint8), 25, (45, 45), True)
     assert e.value.code == _lib.PDOG_E_NODEV and "no CPU path" in str(e.value)
+
+
+def test_window_tile_is_the_padded_view(oracle):
+    """pdog_window_tile (the host-side packer behind pdog_detect_host / pdog_detect_batch_host, no GPU involved)
+    reproduces PaddedView(fill, img, …) (src/PawsomeTracker.jl:45-48) on the rectangle the functor reads:
+    window ± l÷2, any guess up to l÷2 outside the frame, strided frames, padded output pitch."""
+    L = pt.lib()
+    rng = np.random.default_rng(3)
+    for (fh, fw, tw, ws) in ((60, 80, 10, (21, 21)), (50, 40, 25, (45, 45)), (30, 30, 16, (9, 71)), (20, 90, 6, (63, 5)), (7, 5, 25, (45, 45))):
+        wide = rng.integers(0, 256, (fh, fw + 13), dtype=np.uint8)
+        frame = wide[:, :fw]                               # row stride fw + 13
+        l = oracle.kernel_len(oracle.sigma(tw))
+        hw, r1, r2 = l // 2, ws[0] // 2, ws[1] // 2
+        th, tww = 2 * r1 + l, 2 * r2 + l                   # (2r+1) + (l-1)
+        fill = 77
+        padded = np.full((fh + 2 * (r1 + l), fw + 2 * (r2 + l)), fill, np.uint8)   # pad = radii + l per side, :45-46
+        padded[r1 + l:r1 + l + fh, r2 + l:r2 + l + fw] = frame
+        for g in [(-hw, -hw), (fh + hw + 1, fw + hw + 1), (1, 1), (fh, fw), (fh // 2, fw // 2), (-hw, fw), (fh + hw + 1, 1)] + \
+                 [tuple(int(v) for v in rng.integers(-hw, [fh + hw + 2, fw + hw + 2])) for _ in range(20)]:
+            pitch = tww + 11
+            out = np.full((th, pitch), 200, np.uint8)
+            gg = (C.c_int32 * 2)(*g)
+            assert L.pdog_window_tile(frame.ctypes.data, fh, fw, frame.strides[0], fill, float(tw), ws[0], ws[1], gg,
+                                      out.ctypes.data, pitch) == 0
+            i0, j0 = g[0] - r1 - hw - 1 + (r1 + l), g[1] - r2 - hw - 1 + (r2 + l)    # 0-based origin in the padded array
+            assert np.array_equal(out[:, :tww], padded[i0:i0 + th, j0:j0 + tww]), (fh, fw, tw, ws, g)
+            assert (out[:, tww:] == fill).all()
+    bad = (C.c_int32 * 2)(1, 1)
+    assert L.pdog_window_tile(frame.ctypes.data, fh, fw, frame.strides[0], fill, 25.0, 45, 45, bad, out.ctypes.data, 10) == _lib.PDOG_E_ARG
+    assert L.pdog_window_tile(None, fh, fw, fw, fill, 25.0, 45, 45, bad, out.ctypes.data, 200) == _lib.PDOG_E_ARG
