@@ -593,7 +593,8 @@ def test_fused_kernel_batches_and_chains(pt, oracle):
     from oracle.dog_oracle import OracleTracker
     rng = np.random.default_rng(77)
     for tw, ws, (h, w), n in ((25, (45, 45), (240, 320), 40), (25, (31, 57), (120, 90), 24), (10, (21, 21), (100, 140), 300),
-                              (16, (5, 71), (80, 200), 16), (25, (63, 1), (150, 150), 9), (30, (33, 33), (200, 200), 12)):
+                              (16, (5, 71), (80, 200), 16), (25, (63, 1), (150, 150), 9), (30, (33, 33), (200, 200), 12),
+                              (40, (45, 45), (150, 170), 6)):   # l = 101: 155 KB of the 160 KB LDS
         radii = (ws[0] // 2, ws[1] // 2)
         frames, guesses, _ = synth.make_batch(n, h, w, tw, radii, True, seed=int(rng.integers(1 << 30)), noise=3)
         fill = oracle.mode_u8(frames[0])
