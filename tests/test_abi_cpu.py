@@ -103,3 +103,21 @@ def test_window_tile_is_the_padded_view(oracle):
     bad = (C.c_int32 * 2)(1, 1)
     assert L.pdog_window_tile(frame.ctypes.data, fh, fw, frame.strides[0], fill, 25.0, 45, 45, bad, out.ctypes.data, 10) == _lib.PDOG_E_ARG
     assert L.pdog_window_tile(None, fh, fw, fw, fill, 25.0, 45, 45, bad, out.ctypes.data, 200) == _lib.PDOG_E_ARG
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 (and as C++) on its own, and a C translation unit
+    that only includes it must link against the library by name."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "pawsome_dog.h")
+    subprocess.check_call(["gcc", "-x", "c", "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", hdr])
+    subprocess.check_call(["g++", "-x", "c++", "-fsyntax-only", "-Wall", "-Werror", hdr])
+    src = tmp_path / "use.c"
+    src.write_text('#include "pawsome_dog.h"\n#include <stdio.h>\n'
+                   'int main(void) { printf("%d %d %.6f\\n", pdog_abi_version(), pdog_kernel_len(25.0), pdog_sigma(25.0)); return 0; }\n')
+    exe = tmp_path / "use"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)], text=True).split()
+    assert out[0] == "1" and out[1] == "65" and abs(float(out[2]) - 10.616525) < 1e-5

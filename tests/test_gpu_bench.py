@@ -45,3 +45,18 @@ def test_bench_two_rank_rehearsal():
         assert k in r, k
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and "cpu_baseline" not in r
     assert abs(r["value"] - 2 * 128 * 3 / (r["ms_per_step"] * 3e-3)) < 1e-6 * r["value"]
+
+
+def test_plain_c_client_tracks_a_clip(tmp_path):
+    """examples/track_clip.c: the reference's frame loop over the C ABI with no Python in between (compiled with gcc,
+    run as a child process); exit code 0 = every position within a pixel of the moving disc."""
+    sys.path.insert(0, ROOT)
+    from pawsometracker_jl_amd import _lib
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "track_clip")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "track_clip.c"),
+                           "-o", exe, "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib", "-lm"])
+    p = subprocess.run([exe, "80"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stderr[-500:], p.stdout[-200:])
+    assert len(p.stdout.split()) == 160
