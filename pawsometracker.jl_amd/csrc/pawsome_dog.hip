@@ -855,7 +855,7 @@ int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride
         if (t->cap_windows < 1) {
             if (int rc = ensure_capacity(t, 1)) return rc;
         }
-        const int32_t ticket = ++t->ticket;
+        const int32_t ticket = t->ticket = t->ticket % 0x7fffffff + 1;   // 1 … 2^31 − 1, never the mailbox's initial 0
         bool armed = false;
         int rc = launch_detect(t, d_tile, (int64_t)th * pitch, pitch, nullptr, d_mail, 1, d_mail + 2, h_resp ? t->d_resp : nullptr, th, tw,
                                d_mail + 4, ticket, &armed);
