@@ -91,18 +91,41 @@ __global__ __launch_bounds__(256) void dog_h1_kernel(const TwoPassGeo tg, const 
     } else {
         dc = tg.dc[b];
     }
-    // stage 16 tile rows as f32 (pixel − dc); outside the frame = fill − dc
-    for (int r = wave; r < HP_ROWS; r += NW) {
-        const int a = a0 + r, gi = ti0 + a;
-        const bool rowok = (a < tg.NA) && gi >= 0 && gi < g.fh;
-        const uint8_t *src = frame + (long long)gi * g.row_stride;
-        // the row is staged out to the LDS pitch (zeros past the tile): the sliding windows of the last,
-        // partly masked output group then read in-bounds without any per-read clamp
-        for (int c = lane; c < tg.pitchA; c += 64) {
-            const int gj = wj0 + c;
-            int v = g.fill;
-            if (rowok && c < tg.TWin && gj >= 0 && gj < g.fw) v = src[gj];
-            A[r * tg.pitchA + c] = (c < tg.TWin) ? (float)(v - dc) : 0.f;
+    // stage 16 tile rows as f32 (pixel − dc); outside the frame = fill − dc.  The row is staged out to the LDS pitch
+    // (zeros past the tile): the sliding windows of the last, partly masked output group then read in-bounds
+    // without any per-read clamp.  One unaligned dword per 4 pixels, loaded unconditionally at an address clamped
+    // into the frame row (a clamped dword still holds every in-frame byte its group needs, at a shifted position);
+    // the fill is selected afterwards.  (One byte per lane and iteration cost 2 100 issue slots per wave — a third
+    // of them 64-bit scalar address arithmetic — against 4 600 for the whole tap loop.)
+    if (g.fw >= 4) {
+        for (int r = wave; r < HP_ROWS; r += NW) {
+            const int a = a0 + r, gi = ti0 + a;
+            const bool rowok = (a < tg.NA) && gi >= 0 && gi < g.fh;
+            const uint8_t *src = frame + (long long)min(max(gi, 0), g.fh - 1) * g.row_stride;
+            float *dst = A + r * tg.pitchA;
+            for (int c0 = 4 * lane; c0 < tg.pitchA; c0 += 256) {
+                const int gj0 = wj0 + c0, gj0c = min(max(gj0, 0), g.fw - 4);
+                uint32_t w;
+                __builtin_memcpy(&w, src + gj0c, 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = c0 + i, gj = gj0 + i;
+                    const int px = (rowok && gj >= 0 && gj < g.fw) ? (int)((w >> (8 * ((gj - gj0c) & 3))) & 0xffu) : g.fill;
+                    if (c < tg.pitchA) dst[c] = (c < tg.TWin) ? (float)(px - dc) : 0.f;
+                }
+            }
+        }
+    } else {
+        for (int r = wave; r < HP_ROWS; r += NW) {
+            const int a = a0 + r, gi = ti0 + a;
+            const bool rowok = (a < tg.NA) && gi >= 0 && gi < g.fh;
+            const uint8_t *src = frame + (long long)gi * g.row_stride;
+            for (int c = lane; c < tg.pitchA; c += 64) {
+                const int gj = wj0 + c;
+                int v = g.fill;
+                if (rowok && c < tg.TWin && gj >= 0 && gj < g.fw) v = src[gj];
+                A[r * tg.pitchA + c] = (c < tg.TWin) ? (float)(v - dc) : 0.f;
+            }
         }
     }
     __syncthreads();
