@@ -42,6 +42,32 @@ class PdogError(RuntimeError):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 (same SONAMEs as /opt/rocm's) and opens them by
+    path.  If this library were loaded first it would bind to /opt/rocm's copies, `import torch` would then bring
+    in a second HIP runtime, and only the runtime initialised first gets the GPU (seen as "no HIP device" from the
+    other).  Loading torch's copies first makes the order irrelevant: one runtime per process, whichever of the
+    two is imported first.  Without torch installed nothing happens and /opt/rocm's runtime is used."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if not spec or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     """Load the shared library once; fail loudly when it has not been built."""
     global _lib
@@ -51,6 +77,7 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     i, d, p, i64 = C.c_int, C.c_double, C.c_void_p, C.c_int64
     L.pdog_abi_version.restype = i
