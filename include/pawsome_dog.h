@@ -158,6 +158,19 @@ int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_s
                        int64_t row_stride, int n_frames, int n_clips,
                        const int32_t *d_start_guesses, int32_t *d_out_ij);
 
+/* A chain whose positions can be consumed WHILE it runs — what the reference's diagnostic overlay
+ * (src/diagnose.jl:30-38, called per frame inside the loop :163-169) needs from a device-side chain.
+ * h_out_ij (n_frames x 2 int32) and h_progress (one int32) must come from pdog_alloc_host (pinned,
+ * device-mapped, host-coherent; zero-initialised).  *h_progress counts finished frames with release
+ * order: once an acquire load of it returns a value > k, h_out_ij[2k], h_out_ij[2k+1] hold frame k's
+ * position.  Asynchronous on the tracker's stream; d_frames is a device pointer, start_guess a host
+ * pointer.  Same positions as pdog_detect_chain. */
+int pdog_alloc_host(size_t bytes, void **out);
+int pdog_free_host(void *p);
+int pdog_detect_chain_progress(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
+                               int64_t row_stride, int n_frames, const int32_t start_guess[2],
+                               int32_t *h_out_ij, int32_t *h_progress);
+
 #ifdef __cplusplus
 }
 #endif

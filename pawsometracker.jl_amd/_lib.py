@@ -18,6 +18,7 @@ SYMBOLS = (
     "pdog_gaussian_taps", "pdog_mode_u8", "pdog_mode_u8_device", "pdog_create", "pdog_destroy", "pdog_get_info",
     "pdog_set_fill", "pdog_set_stream", "pdog_reserve", "pdog_set_variant", "pdog_sync",
     "pdog_detect_batch", "pdog_detect_host", "pdog_window_tile", "pdog_detect_batch_host", "pdog_detect_chain", "pdog_detect_chains",
+    "pdog_alloc_host", "pdog_free_host", "pdog_detect_chain_progress",
 )
 
 
@@ -105,6 +106,10 @@ def lib():
         L.pdog_window_tile.restype = i; L.pdog_window_tile.argtypes = [p, i, i, i64, i, d, i, i, p, p, i64]
     if hasattr(L, "pdog_detect_batch_host"):
         L.pdog_detect_batch_host.restype = i; L.pdog_detect_batch_host.argtypes = [p, p, i64, i64, i, p, p, i, p]
+    if hasattr(L, "pdog_detect_chain_progress"):
+        L.pdog_alloc_host.restype = i; L.pdog_alloc_host.argtypes = [C.c_size_t, C.POINTER(p)]
+        L.pdog_free_host.restype = i; L.pdog_free_host.argtypes = [p]
+        L.pdog_detect_chain_progress.restype = i; L.pdog_detect_chain_progress.argtypes = [p, p, i64, i64, i, p, p, p]
     if hasattr(L, "pdog_detect_chains"):  # absent only in older A/B builds selected through PAWSOME_DOG_LIB
         L.pdog_detect_chains.restype = i; L.pdog_detect_chains.argtypes = [p, p, i64, i64, i, i, p, p]
     _lib = L

@@ -102,6 +102,19 @@ class BatchTracker:
                                                 frames.stride(1), n, g, C.c_void_p(out.data_ptr())))
         return out
 
+    def detect_chain_progress(self, frames, start_guess):
+        """detect_chain whose positions land in host memory as the frames finish (pdog_detect_chain_progress): returns a
+        ChainProgress to poll — what a per-frame consumer such as the reference's diagnostic overlay
+        (src/diagnose.jl:30-38) needs from a device-side chain."""
+        import torch
+        self.use_torch_stream()
+        assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3 and frames.stride(2) == 1
+        cp = ChainProgress(self, frames.shape[0], frames)
+        g = (C.c_int32 * 2)(int(start_guess[0]), int(start_guess[1]))
+        _lib.check(_lib.lib().pdog_detect_chain_progress(self._h, C.c_void_p(frames.data_ptr()), frames.stride(0), frames.stride(1),
+                                                         frames.shape[0], g, cp._out_ptr, cp._prog_ptr))
+        return cp
+
     def detect_chains(self, frames, start_guesses, out=None):
         """Many clips at once (one persistent launch for l = 65): frames uint8 cuda [n_clips, n_frames, h, w],
         start_guesses int32 cuda [n_clips, 2]; returns int32 cuda [n_clips, n_frames, 2]."""
@@ -127,6 +140,36 @@ class BatchTracker:
             self.close()
         except Exception:
             pass
+
+
+class ChainProgress:
+    """Host-visible state of a running chain: `done()` frames are finished and `positions[:done()]` are final
+    (the library publishes the count with release order; numpy reads the pinned words afresh on every access)."""
+
+    def __init__(self, bt, n_frames, keepalive=None):
+        import numpy as np
+        self._bt, self.n_frames, self._keepalive = bt, int(n_frames), keepalive
+        out, prog = C.c_void_p(), C.c_void_p()
+        _lib.check(_lib.lib().pdog_alloc_host(8 * self.n_frames, C.byref(out)))
+        _lib.check(_lib.lib().pdog_alloc_host(4, C.byref(prog)))
+        self._out_ptr, self._prog_ptr = out, prog
+        self.positions = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int32)), shape=(self.n_frames, 2))
+        self._prog = np.ctypeslib.as_array(C.cast(prog, C.POINTER(C.c_int32)), shape=(1,))
+
+    def done(self):
+        return int(self._prog[0])
+
+    def wait(self):
+        self._bt.sync()
+        return self.positions.copy()
+
+    def close(self):
+        if self._out_ptr is not None:
+            self._bt.sync()
+            self.positions = self._prog = None
+            _lib.lib().pdog_free_host(self._out_ptr)
+            _lib.lib().pdog_free_host(self._prog_ptr)
+            self._out_ptr = self._prog_ptr = None
 
 
 def mode_device(frame):

@@ -31,6 +31,7 @@ struct FusedGeo {
     int32_t *out_ij;     // [n][chain_len][2], clamped to the frame
     int32_t *done_flag;  // NULL, or a word in host-coherent memory that receives done_value (system-scope release) once
     int32_t done_value;  // window 0's answer is written: the host functor polls it instead of waiting for the kernel's end
+    int progress;        // != 0: done_flag receives k + 1 after every frame k of clip 0 instead (a host consumer follows the chain)
 };
 
 constexpr int FUSED_NT = 1024, FUSED_PMAX = 8, FUSED_U = 8;
@@ -297,8 +298,8 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
                 o[1] = j;
                 s_guess[0] = i;
                 s_guess[1] = j;
-                if (fg.done_flag && b == 0 && k == fg.chain_len - 1)
-                    __hip_atomic_store(fg.done_flag, fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (fg.done_flag && b == 0 && (fg.progress || k == fg.chain_len - 1))
+                    __hip_atomic_store(fg.done_flag, fg.progress ? k + 1 : fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         __syncthreads();
@@ -306,6 +307,12 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
         g1 = s_guess[0];   // :167 — the next frame's guess
         g2 = s_guess[1];
     }
+}
+
+// frames finished so far, for paths whose own kernels do not publish it (see pdog_detect_chain_progress)
+__global__ void dog_publish_kernel(int32_t *flag, int32_t value)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 } // namespace pdog

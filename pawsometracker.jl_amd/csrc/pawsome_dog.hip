@@ -337,7 +337,7 @@ fused_fn_t fused_kernel_for(int L, bool resp)
 // One workgroup per window (chain_len = 1) or per clip (chain_len frames, frame k > 0 starts at frame k−1's answer).
 int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
                  const int32_t *d_frame_index, const int32_t *d_guesses, int n, int chain_len, int32_t *d_out_ij,
-                 float *d_out_resp, int FH, int FW, int32_t *d_done_flag = nullptr, int32_t done_value = 0)
+                 float *d_out_resp, int FH, int FW, int32_t *d_done_flag = nullptr, int32_t done_value = 0, bool progress = false)
 {
     FusedGeo fg;
     LaunchGeo &g = fg.g;
@@ -378,6 +378,7 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     fg.out_ij = d_out_ij;
     fg.done_flag = d_done_flag;
     fg.done_value = done_value;
+    fg.progress = progress ? 1 : 0;
     const size_t lds = fused_lds_bytes(t->n1, t->n2, t->L);
     typedef fused_fn_t fused_fn;
     fused_fn fn = fused_kernel_for(t->L, d_out_resp != nullptr);
@@ -1205,3 +1206,52 @@ extern "C" int pdog_detect_chain(pdog_tracker *t, const uint8_t *d_frames, int64
     return pdog_detect_chains(t, d_frames, frame_stride, row_stride, n_frames, 1, t->d_small, d_out_ij);
 }
 
+
+// ---- a chain whose positions can be consumed while it runs (the reference's Diagnose overlay,
+// src/diagnose.jl:30-38, draws frame k as soon as ij[k] exists) ----
+extern "C" int pdog_alloc_host(size_t bytes, void **out)
+{
+    if (!out || bytes == 0) return fail(PDOG_E_ARG, "pdog_alloc_host: bad argument");
+    void *p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(p, 0, bytes);
+    *out = p;
+    return PDOG_OK;
+}
+
+extern "C" int pdog_free_host(void *p)
+{
+    if (p) HIP_TRY(hipHostFree(p));
+    return PDOG_OK;
+}
+
+extern "C" int pdog_detect_chain_progress(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
+                                          int n_frames, const int32_t start_guess[2], int32_t *h_out_ij, int32_t *h_progress)
+{
+    if (!t || !d_frames || !start_guess || !h_out_ij || !h_progress) return fail(PDOG_E_ARG, "pdog_detect_chain_progress: null pointer");
+    if (n_frames <= 0 || row_stride < t->fw || frame_stride < 0) return fail(PDOG_E_ARG, "pdog_detect_chain_progress: bad size/stride");
+    HIP_TRY(hipSetDevice(t->device));
+    int32_t *d_out = nullptr, *d_prog = nullptr;
+    if (hipHostGetDevicePointer((void **)&d_out, h_out_ij, 0) != hipSuccess || hipHostGetDevicePointer((void **)&d_prog, h_progress, 0) != hipSuccess)
+        return fail(PDOG_E_ARG, "pdog_detect_chain_progress: h_out_ij / h_progress must come from pdog_alloc_host");
+    __atomic_store_n(h_progress, 0, __ATOMIC_RELEASE);
+    HIP_TRY(hipMemcpyAsync(t->d_small, start_guess, sizeof(int32_t) * 2, hipMemcpyHostToDevice, t->stream));
+    if (t->var->fused || (!t->forced_variant && t->fused_ok)) // one launch: the kernel publishes k + 1 after every frame
+        return launch_fused(t, d_frames, frame_stride, row_stride, nullptr, t->d_small, 1, n_frames, d_out, nullptr, t->fh, t->fw,
+                            d_prog, 0, true);
+    if (t->cap_windows < 1) {
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        if (int rc = ensure_capacity(t, 1)) return rc;
+    }
+    for (int k = 0; k < n_frames; ++k) { // stream-ordered launches per frame; frame k's guess is read from the (host-mapped) answer k − 1
+        bool armed = false;
+        int rc = launch_detect(t, d_frames + (int64_t)k * frame_stride, frame_stride, row_stride, nullptr, k ? d_out + 2 * (k - 1) : t->d_small, 1,
+                               d_out + 2 * k, nullptr, 0, 0, d_prog, k + 1, &armed);
+        if (rc) return rc;
+        if (!armed) {
+            hipLaunchKernelGGL(dog_publish_kernel, dim3(1), dim3(64), 0, t->stream, d_prog, k + 1);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return PDOG_OK;
+}

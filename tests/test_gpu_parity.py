@@ -677,3 +677,36 @@ def test_identical_targets_tie_goes_to_the_first_in_column_major_order(pt, oracl
         tr = pt.Tracker(f, tw, ws, False)
         assert tr(guess) == exp
         tr.close()
+
+
+def test_chain_progress_can_be_followed_from_the_host(pt, oracle):
+    """pdog_detect_chain_progress: the chain's positions land in host-coherent memory frame by frame with a release-
+    ordered counter, so a per-frame consumer (the reference's diagnostic overlay) can follow a device-side chain.
+    Whatever prefix the host observes while the chain runs must already be final; the whole result equals
+    pdog_detect_chain's.  Fused path (45x45) and per-frame-launch path (129x129 window, two-pass kernels)."""
+    import time
+    import torch
+    from oracle import synth
+    rng = np.random.default_rng(5)
+    for ws, nf in (((45, 45), 400), ((129, 129), 120)):
+        h, w, tw = 300, 400, 25
+        pos = np.clip(np.cumsum(rng.integers(-6, 7, (nf, 2)), 0) + np.array([h // 2, w // 2]), 20, [h - 20, w - 20])
+        fr = np.stack([synth.disc_frame(h, w, (int(p[0]), int(p[1])), tw, True) for p in pos])
+        d_fr = torch.from_numpy(fr).cuda()
+        bt = pt.BatchTracker(h, w, tw, ws, True, 128)
+        start = (int(pos[0][0]) + 2, int(pos[0][1]) - 3)
+        ref = bt.detect_chain(d_fr, start).cpu().numpy()
+        assert np.array_equal(ref, pos.astype(np.int32))          # noise-free discs: the chain follows the centres exactly
+        cp = bt.detect_chain_progress(d_fr, start)
+        seen, snapshots = 0, 0
+        t0 = time.perf_counter()
+        while seen < nf and time.perf_counter() - t0 < 30:
+            k = cp.done()
+            assert seen <= k <= nf
+            if k > seen:
+                assert np.array_equal(cp.positions[:k], ref[:k]), (ws, k)     # every published prefix is final
+                snapshots += 1
+                seen = k
+        assert seen == nf and np.array_equal(cp.wait(), ref)
+        cp.close()
+        bt.close()
