@@ -710,3 +710,56 @@ def test_chain_progress_can_be_followed_from_the_host(pt, oracle):
         assert seen == nf and np.array_equal(cp.wait(), ref)
         cp.close()
         bt.close()
+
+
+def test_seeded_fuzz_every_entry_point_vs_oracle(pt, oracle):
+    """120 seeded random configurations — frames from 1x1 to 90x120 (narrower than a dword, smaller than the kernel,
+    smaller than the window), target widths 2…40, odd window shapes, guesses up to l÷2 outside the frame, random
+    textures with discs, bright and dark targets — through every entry point that returns a position: the functor
+    (in-place tile), the device batch (automatic kernel choice), the host batch and the single-clip chain."""
+    import torch
+    from oracle import synth
+    rng = np.random.default_rng(424242)
+    for case in range(120):
+        fh, fw = int(rng.integers(1, 91)), int(rng.integers(1, 121))
+        if case % 10 == 0:
+            fw = int(rng.integers(1, 4))                         # narrower than one dword
+        tw = float(rng.choice([2, 3, 5, 8, 10, 13, 16, 20, 25, 33, 40]))
+        ws = (int(rng.integers(1, 60)), int(rng.integers(1, 80)))
+        darker = bool(rng.integers(0, 2))
+        radii = (ws[0] // 2, ws[1] // 2)
+        l = oracle.kernel_len(oracle.sigma(tw))
+        hw = l // 2
+        if (2 * radii[0] + l) * (2 * radii[1] + l) * l * l > 4e9:   # keep the dense oracle affordable
+            continue
+        n = 5
+        frames = rng.integers(100, 156, (n, fh, fw)).astype(np.uint8)
+        for b in range(n):
+            ci, cj = int(rng.integers(1, fh + 1)), int(rng.integers(1, fw + 1))
+            disc = synth.disc_frame(fh, fw, (ci, cj), max(2, int(tw)), darker)
+            mask = disc != 128
+            frames[b][mask] = disc[mask]
+        guesses = np.stack([rng.integers(-hw, fh + hw + 2, n), rng.integers(-hw, fw + hw + 2, n)], 1).astype(np.int32)
+        fill = oracle.mode_u8(frames[0])
+        K = oracle.dog_kernel(oracle.sigma(tw), darker)
+        exp = oracle.detect_batch(frames, fill, K, radii, guesses)
+        tag = (case, fh, fw, tw, ws, darker)
+        bt = pt.BatchTracker(fh, fw, tw, ws, darker, fill)
+        d_frames = torch.from_numpy(frames).cuda()
+        got = bt.detect(d_frames, torch.from_numpy(guesses).cuda()).cpu().numpy()
+        assert np.array_equal(got, exp), ("batch",) + tag
+        assert np.array_equal(bt.detect_host(frames, guesses), exp), ("host batch",) + tag
+        # chain on the first frame repeated: each step starts from the previous answer
+        rep = np.repeat(frames[:1], 3, 0)
+        chain = bt.detect_chain(torch.from_numpy(rep).cuda(), (int(guesses[0, 0]), int(guesses[0, 1]))).cpu().numpy()
+        g = (int(guesses[0, 0]), int(guesses[0, 1]))
+        for k in range(3):
+            g = oracle.detect(frames[0], fill, K, radii, g)
+            assert tuple(int(v) for v in chain[k]) == g, ("chain", k) + tag
+        bt.close()
+        tr = pt.Tracker(frames[0], tw, ws, darker)
+        assert tr.img.fillvalue == fill
+        for b in range(n):
+            tr.img.data[...] = frames[b]
+            assert tr((int(guesses[b, 0]), int(guesses[b, 1]))) == tuple(int(v) for v in exp[b]), ("functor", b) + tag
+        tr.close()
