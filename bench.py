@@ -246,7 +246,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "frame": [fh, fw], "window": [info.win_h, info.win_w],
                        "batch_per_gpu": batch, "target_width": tw, "kernel_len": info.kernel_len,
-                       "noise_levels": args.noise, "variant": info.variant, "strips": info.n_strips,
+                       "noise_levels": args.noise, "variant": info.variant, "kernel_for_this_batch": bt.kernel_for_batch(batch),
+                       "strips": info.n_strips,
                        "sharding": (f"frames x{world}, gather int32[n,2] to rank 0" + ("" if backend == "nccl" else f" ({backend} rehearsal)"))
                                    if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

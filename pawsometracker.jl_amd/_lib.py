@@ -16,7 +16,7 @@ PDOG_OK, PDOG_E_ARG, PDOG_E_HIP, PDOG_E_NODEV, PDOG_E_RANGE, PDOG_E_ALLOC = rang
 SYMBOLS = (
     "pdog_abi_version", "pdog_last_error", "pdog_sigma", "pdog_default_window", "pdog_kernel_len",
     "pdog_gaussian_taps", "pdog_mode_u8", "pdog_mode_u8_device", "pdog_create", "pdog_destroy", "pdog_get_info",
-    "pdog_set_fill", "pdog_set_stream", "pdog_reserve", "pdog_set_variant", "pdog_sync",
+    "pdog_set_fill", "pdog_set_stream", "pdog_reserve", "pdog_set_variant", "pdog_kernel_for_batch", "pdog_sync",
     "pdog_detect_batch", "pdog_detect_host", "pdog_window_tile", "pdog_detect_batch_host", "pdog_detect_chain", "pdog_detect_chains",
     "pdog_alloc_host", "pdog_free_host", "pdog_detect_chain_progress",
 )
@@ -102,6 +102,8 @@ def lib():
     L.pdog_detect_batch.argtypes = [p, p, i64, i64, i, p, p, i, p, p]
     L.pdog_detect_host.restype = i; L.pdog_detect_host.argtypes = [p, p, i64, p, p, p]
     L.pdog_detect_chain.restype = i; L.pdog_detect_chain.argtypes = [p, p, i64, i64, i, p, p]
+    if hasattr(L, "pdog_kernel_for_batch"):
+        L.pdog_kernel_for_batch.restype = i; L.pdog_kernel_for_batch.argtypes = [p, i, C.POINTER(i)]
     if hasattr(L, "pdog_window_tile"):
         L.pdog_window_tile.restype = i; L.pdog_window_tile.argtypes = [p, i, i, i64, i, d, i, i, p, p, i64]
     if hasattr(L, "pdog_detect_batch_host"):

@@ -29,6 +29,12 @@ class BatchTracker:
     def set_variant(self, variant):
         _lib.check(_lib.lib().pdog_set_variant(self._h, int(variant)))
 
+    def kernel_for_batch(self, n):
+        """Variant id of the kernel family a batch of n windows runs on (300 fused, 200 two-pass, else info().variant)."""
+        o = C.c_int()
+        _lib.check(_lib.lib().pdog_kernel_for_batch(self._h, int(n), C.byref(o)))
+        return o.value
+
     def reserve(self, n):
         _lib.check(_lib.lib().pdog_reserve(self._h, int(n)))
 

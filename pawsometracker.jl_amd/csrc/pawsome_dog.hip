@@ -334,6 +334,22 @@ fused_fn_t fused_kernel_for(int L, bool resp)
     return resp ? (fused_fn_t)dog_fused_kernel<true> : (fused_fn_t)dog_fused_kernel<false>;
 }
 
+// Which kernel family a batch of n windows runs on (variant ids: 300 fused, 200 two-pass, otherwise the tracker's
+// batch kernel).  A batch of fewer than ≈1000 strip-waves cannot fill 256 CUs × 8 waves with one wave per strip:
+// windows that fit in LDS then go to the fused kernel (one workgroup per window, one launch), larger ones to the
+// two-pass kernels (dozens of workgroups per window).  pdog_set_variant pins the tracker's kernel.
+constexpr int kPathFused = 300, kPathTwoPass = 200;
+int path_for_batch(const pdog_tracker *t, int n)
+{
+    const Variant &v = *t->var;
+    if (v.fused) return kPathFused;
+    if (t->forced_variant) return v.twopass ? kPathTwoPass : v.id;
+    const bool few = v.twopass ? n <= 256 : (long long)n * (t->nstrips + (t->nthin ? 1 : 0)) < 1000;
+    if (few && t->fused_ok) return kPathFused;
+    if (v.twopass || (few && t->small_twopass)) return kPathTwoPass;
+    return v.id;
+}
+
 // One workgroup per window (chain_len = 1) or per clip (chain_len frames, frame k > 0 starts at frame k−1's answer).
 int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
                  const int32_t *d_frame_index, const int32_t *d_guesses, int n, int chain_len, int32_t *d_out_ij,
@@ -420,16 +436,14 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     g.thin_x0 = t->thin_x0;
     g.nthin = t->nthin;
     // windows that fit in LDS, in batches too small to fill the GPU any other way: one workgroup per window, one launch
-    if (v.fused || (!t->forced_variant && t->fused_ok &&
-                    (v.twopass ? n <= 256 : (long long)n * (t->nstrips + (t->nthin ? 1 : 0)) < 1000)))
-    {
+    const int path = path_for_batch(t, n);
+    if (path == kPathFused) {
         if (ticket_armed) *ticket_armed = d_done_flag != nullptr;
         return launch_fused(t, d_frames, frame_stride, row_stride, d_frame_index, d_guesses, n, 1, d_out_ij, d_out_resp, FH, FW,
                             d_done_flag, done_value);
     }
     // small batches: fewer than ≈1000 strip-waves cannot fill 256 CUs × 8 waves; the two-pass kernels can
-    const bool small = !v.twopass && !t->forced_variant && t->small_twopass && (long long)n * (t->nstrips + (t->nthin ? 1 : 0)) < 1000;
-    if (v.twopass || small) {
+    if (path == kPathTwoPass) {
         const int hr = std::getenv("PDOG_HPASS16") ? HP_ROWS : 8; // 8 RT rows per workgroup (32 KB LDS → 4 workgroups per CU): +3 % on cfg5 vs 16; env = tuning switch
         const int tp_slots = (t->n2 + hr - 1) / hr; // partial slots = hr-column blocks
         g.nstrips = tp_slots;
@@ -759,6 +773,13 @@ int pdog_get_info(const pdog_tracker *t, pdog_info *o)
     const int64_t th = t->n1 + t->L - 1, tw = t->n2 + t->L - 1;
     o->algorithmic_bytes_per_window = th * tw + 8;
     o->algorithmic_fma_per_window = 2LL * t->L * (th * t->n2 + (int64_t)t->n1 * t->n2);
+    return PDOG_OK;
+}
+
+int pdog_kernel_for_batch(const pdog_tracker *t, int n, int *out_variant)
+{
+    if (!t || !out_variant || n < 0) return fail(PDOG_E_ARG, "pdog_kernel_for_batch: bad argument");
+    *out_variant = path_for_batch(t, n);
     return PDOG_OK;
 }
 

@@ -763,3 +763,17 @@ def test_seeded_fuzz_every_entry_point_vs_oracle(pt, oracle):
             tr.img.data[...] = frames[b]
             assert tr((int(guesses[b, 0]), int(guesses[b, 1]))) == tuple(int(v) for v in exp[b]), ("functor", b) + tag
         tr.close()
+
+
+def test_kernel_for_batch_reports_the_launch_time_switch(pt):
+    bt = pt.BatchTracker(1080, 1920, 25, (45, 45), True, 128)
+    assert bt.info().variant == 100 and bt.kernel_for_batch(1) == 300 and bt.kernel_for_batch(999) == 300 and bt.kernel_for_batch(4096) == 100
+    bt.set_variant(100)
+    assert bt.kernel_for_batch(1) == 100
+    bt.close()
+    bt = pt.BatchTracker(1080, 1920, 25, (256, 256), True, 128)
+    assert bt.kernel_for_batch(1) == 200 and bt.kernel_for_batch(64) == 200 and bt.kernel_for_batch(4096) == 100
+    bt.close()
+    bt = pt.BatchTracker(1080, 1920, 120, (205, 205), True, 128)
+    assert bt.info().variant == 200 and bt.kernel_for_batch(1) == 200 and bt.kernel_for_batch(4096) == 200
+    bt.close()
