@@ -253,6 +253,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": stored_traffic(args.workload, info.variant, batch),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_window": abytes,
+                         # what `frac` would be with the FP32 vector ALUs 100 % busy on algorithmic FMAs: the ceiling of this path
+                         "frac_at_fp32_vector_peak": abytes / (afma / VALU_PEAK_FMA) / 1e9 / HBM_PEAK_GBS,
                          "valu": {"achieved_fma_per_s": fma_rate, "peak_fma_per_s": VALU_PEAK_FMA,
                                   "frac": fma_rate / VALU_PEAK_FMA, "algorithmic_fma_per_window": afma},
                          "note": "path is FP32-VALU bound (375 flop/B vs ridge 19.7, DESIGN.md); traffic = FETCH_SIZE x2 (gfx950 "
