@@ -16,6 +16,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <atomic>
+#include <emmintrin.h>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -936,25 +937,39 @@ namespace {
 // PaddedView fill (:48) materialised wherever the rectangle leaves the frame.  Tile row a, column b is the
 // padded frame at 1-based (g1 - r1 - l÷2 + a, g2 - r2 - l÷2 + b).
 void pack_tile_geo(const uint8_t *frame, int fh, int fw, int64_t row_stride, int fill, int L, int r1, int r2, int g1, int g2,
-                   uint8_t *dst, int64_t pitch)
+                   uint8_t *dst, int64_t pitch, bool stream = false)
 {
     const int hw = L >> 1, th = 2 * r1 + 1 + 2 * hw, tw = 2 * r2 + 1 + 2 * hw;
     const int i0 = g1 - r1 - hw - 1, j0 = g2 - r2 - hw - 1;        // 0-based frame coordinates of tile (0, 0)
     const int jl = std::min(tw, std::max(0, -j0));                 // columns left of the frame
     const int jr = std::max(jl, std::min(tw, fw - j0));            // first column right of the frame
+    // stream: the tile goes to pinned staging that only the DMA engine reads next — assemble each row in a small
+    // buffer and write it with non-temporal stores, so the copy engine finds the data in DRAM instead of having to
+    // snoop dirty lines out of this core's cache
+    const bool nt = stream && pitch % 16 == 0 && pitch <= 4096 && ((uintptr_t)dst & 15) == 0;
+    alignas(16) uint8_t rowbuf[4096];
     for (int a = 0; a < th; ++a) {
-        uint8_t *row = dst + (size_t)a * pitch;
+        uint8_t *out = dst + (size_t)a * pitch;
+        uint8_t *row = nt ? rowbuf : out;
         const int gi = i0 + a;
-        if (gi < 0 || gi >= fh) { std::memset(row, fill, (size_t)pitch); continue; }
-        if (jl) std::memset(row, fill, (size_t)jl);
-        if (jr > jl) std::memcpy(row + jl, frame + (size_t)gi * row_stride + (j0 + jl), (size_t)(jr - jl));
-        if (pitch > jr) std::memset(row + jr, fill, (size_t)(pitch - jr));
+        if (gi < 0 || gi >= fh) {
+            std::memset(row, fill, (size_t)pitch);
+        } else {
+            if (jl) std::memset(row, fill, (size_t)jl);
+            if (jr > jl) std::memcpy(row + jl, frame + (size_t)gi * row_stride + (j0 + jl), (size_t)(jr - jl));
+            if (pitch > jr) std::memset(row + jr, fill, (size_t)(pitch - jr));
+        }
+        if (nt)
+            for (int64_t k = 0; k < pitch; k += 16)
+                _mm_stream_si128((__m128i *)(out + k), _mm_load_si128((const __m128i *)(rowbuf + k)));
     }
+    if (nt) _mm_sfence(); // the non-temporal stores are globally visible before the caller publishes the tile
 }
 
 void pack_tile(const pdog_tracker *t, const uint8_t *frame, int64_t row_stride, int g1, int g2, uint8_t *dst, int pitch)
 {
-    pack_tile_geo(frame, t->fh, t->fw, row_stride, t->fill, t->L, t->r1, t->r2, g1, g2, dst, pitch);
+    // cached stores: the functor's kernel reads this tile in place right away (non-temporal stores measured equal here)
+    pack_tile_geo(frame, t->fh, t->fw, row_stride, t->fill, t->L, t->r1, t->r2, g1, g2, dst, pitch, false);
 }
 
 } // namespace
@@ -1082,8 +1097,9 @@ extern "C" int pdog_detect_batch_host(pdog_tracker *t, const uint8_t *h_frames, 
                 waited_for = c;
             }
             const int f = h_frame_index ? h_frame_index[b] : b;
-            pack_tile(t, h_frames + (int64_t)f * frame_stride, row_stride, h_guesses[2 * b], h_guesses[2 * b + 1],
-                      t->h_stage[c % NS] + (size_t)(b - c * chunk) * tile_bytes, pitch);
+            static const bool nt_stores = std::getenv("PDOG_INGEST_NO_NT") == nullptr;
+            pack_tile_geo(h_frames + (int64_t)f * frame_stride, t->fh, t->fw, row_stride, t->fill, t->L, t->r1, t->r2,
+                          h_guesses[2 * b], h_guesses[2 * b + 1], t->h_stage[c % NS] + (size_t)(b - c * chunk) * tile_bytes, pitch, nt_stores);
             packed[c].fetch_add(1, std::memory_order_release);
         }
     };
