@@ -777,3 +777,25 @@ def test_kernel_for_batch_reports_the_launch_time_switch(pt):
     bt = pt.BatchTracker(1080, 1920, 120, (205, 205), True, 128)
     assert bt.info().variant == 200 and bt.kernel_for_batch(1) == 200 and bt.kernel_for_batch(4096) == 200
     bt.close()
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4", "cfg5"])
+def test_full_size_one_noisy_window_vs_dense_oracle(pt, oracle, cfg):
+    """One noisy window of every BASELINE.json geometry at FULL frame, window and kernel size against the dense
+    Float64 oracle (0.3 … 3.6 G MAC each): position exact, response within 1e-5 of max|ref| — through the batch
+    kernels that the large batches of the bench use (kernel pinned) and through the small-batch path."""
+    from oracle import synth
+    fh, fw, tw, ws = {"cfg2": (1080, 1920, 25, (270, 480)), "cfg3": (1080, 1920, 25, (256, 256)),
+                      "cfg4": (2160, 3840, 25, (512, 512)), "cfg5": (1080, 1920, 120, (205, 205))}[cfg]
+    radii = (ws[0] // 2, ws[1] // 2)
+    frames, guesses, _ = synth.make_batch(1, fh, fw, tw, radii, True, seed=77, noise=3)
+    fill = oracle.mode_u8(frames[0])
+    K = oracle.dog_kernel(oracle.sigma(tw), True)
+    ij, ref = oracle.detect(frames[0], fill, K, radii, guesses[0], want_resp=True)
+    bt = pt.BatchTracker(fh, fw, tw, ws, True, fill)
+    main = bt.info().variant
+    bt.close()
+    for variant in (None, main):
+        got, resp = _batch(pt, frames, guesses, tw, ws, True, fill, want_resp=True, variant=variant)
+        assert tuple(int(v) for v in got[0]) == ij, (cfg, variant)
+        _check_resp(resp[0].T, ref, f"{cfg} full size variant {variant}")
