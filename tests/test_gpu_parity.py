@@ -799,3 +799,42 @@ def test_full_size_one_noisy_window_vs_dense_oracle(pt, oracle, cfg):
         got, resp = _batch(pt, frames, guesses, tw, ws, True, fill, want_resp=True, variant=variant)
         assert tuple(int(v) for v in got[0]) == ij, (cfg, variant)
         _check_resp(resp[0].T, ref, f"{cfg} full size variant {variant}")
+
+
+def test_translation_covariance_full_size(pt, oracle):
+    """Shifting a frame and the guess by (di, dj) shifts the answer by (di, dj) and leaves the response bit-identical —
+    whatever the new alignment of the tile to 4/16-byte loads, strips and sub-chunks.  1080p, 257x257 windows, noisy
+    frames; windows kept clear of the frame border so that the wrap-around of np.roll never enters a tile."""
+    import torch
+    rng = np.random.default_rng(8)
+    fh, fw, tw, ws, n = 1080, 1920, 25, (256, 256), 24
+    frames = rng.integers(118, 139, (n, fh, fw)).astype(np.uint8)
+    guesses = np.stack([rng.integers(400, fh - 400, n), rng.integers(400, fw - 400, n)], 1).astype(np.int32)
+    from oracle import synth
+    for b in range(n):
+        c = guesses[b] + rng.integers(-60, 61, 2)
+        disc = synth.disc_frame(fh, fw, (int(c[0]), int(c[1])), tw, True)
+        frames[b][disc != 128] = 0
+    fill = 128
+    for variant in (100, 200, 10):          # roll kernel (what large batches run), two-pass, a ring kernel
+        bt = pt.BatchTracker(fh, fw, tw, ws, True, fill)
+        bt.set_variant(variant)
+        base, base_resp = bt.detect(torch.from_numpy(frames).cuda(), torch.from_numpy(guesses).cuda(), want_resp=True)
+        base, base_resp = base.cpu().numpy(), base_resp.cpu().numpy()
+        for (di, dj) in ((1, 1), (0, 3), (7, -5), (-13, 16), (31, -33), (-64, 64), (2, 129)):
+            shifted = np.roll(frames, (di, dj), axis=(1, 2))
+            g2 = guesses + np.array([di, dj], np.int32)
+            got, resp = bt.detect(torch.from_numpy(shifted).cuda(), torch.from_numpy(g2).cuda(), want_resp=True)
+            assert np.array_equal(got.cpu().numpy(), base + np.array([di, dj], np.int32)), (variant, di, dj)
+            assert np.array_equal(resp.cpu().numpy(), base_resp), (variant, di, dj)          # bit-identical response
+        bt.close()
+    # the same for the small-batch kernels (one window: two-pass; 45x45: fused)
+    for ws2 in ((256, 256), (45, 45)):
+        bt = pt.BatchTracker(fh, fw, tw, ws2, True, fill)
+        b0, r0 = bt.detect(torch.from_numpy(frames[:1]).cuda(), torch.from_numpy(guesses[:1]).cuda(), want_resp=True)
+        for (di, dj) in ((3, 2), (-17, 9)):
+            sh = np.roll(frames[:1], (di, dj), axis=(1, 2))
+            b1, r1 = bt.detect(torch.from_numpy(sh).cuda(), torch.from_numpy(guesses[:1] + np.array([di, dj], np.int32)).cuda(), want_resp=True)
+            assert np.array_equal(b1.cpu().numpy(), b0.cpu().numpy() + np.array([di, dj], np.int32))
+            assert torch.equal(r1, r0)
+        bt.close()
