@@ -838,3 +838,29 @@ def test_translation_covariance_full_size(pt, oracle):
             assert np.array_equal(b1.cpu().numpy(), b0.cpu().numpy() + np.array([di, dj], np.int32))
             assert torch.equal(r1, r0)
         bt.close()
+
+
+def test_power_of_two_contrast_scales_the_response_exactly(pt):
+    """The path is linear in (pixel - dc) and FP32 scaling by 2 is exact: doubling every pixel's distance from the
+    fill value doubles the response bit for bit and leaves the position unchanged (as long as the window's DC level
+    stays the fill value: sparse target, balanced noise).  No oracle involved."""
+    import torch
+    from oracle import synth
+    rng = np.random.default_rng(12)
+    for (fh, fw, tw, ws, n, variant) in ((600, 800, 25, (256, 256), 6, 100), (600, 800, 25, (256, 256), 6, 200),
+                                         (300, 400, 25, (45, 45), 10, 300), (400, 500, 120, (101, 101), 3, 200)):
+        fill = 128
+        frames = (fill + rng.integers(-2, 3, (n, fh, fw))).astype(np.uint8)
+        guesses = np.stack([rng.integers(fh // 3, 2 * fh // 3, n), rng.integers(fw // 3, 2 * fw // 3, n)], 1).astype(np.int32)
+        for b in range(n):
+            c = guesses[b] + rng.integers(-15, 16, 2)
+            disc = synth.disc_frame(fh, fw, (int(c[0]), int(c[1])), tw, True)
+            frames[b][disc != 128] = fill - 50
+        doubled = (fill + 2 * (frames.astype(np.int16) - fill)).astype(np.uint8)
+        bt = pt.BatchTracker(fh, fw, tw, ws, True, fill)
+        bt.set_variant(variant)
+        p1, r1 = bt.detect(torch.from_numpy(frames).cuda(), torch.from_numpy(guesses).cuda(), want_resp=True)
+        p2, r2 = bt.detect(torch.from_numpy(doubled).cuda(), torch.from_numpy(guesses).cuda(), want_resp=True)
+        assert torch.equal(p1, p2), variant
+        assert torch.equal(r2, 2 * r1), variant
+        bt.close()
