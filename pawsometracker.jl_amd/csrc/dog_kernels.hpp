@@ -1,7 +1,7 @@
 // dog_kernels.hpp — gfx950 (CDNA4) device code for the DoG + argmax hot path: shared definitions
 // (LaunchGeo, tap access, the per-window DC level, the strip combine) and the LDS-ring kernel, the first
 // kernel of this repo.  Today the ring kernel serves kernel lengths l < 17 and is the second implementation
-// the parity tests compare against; l = 17…77 runs dog_roll.hpp, l ≥ 80 dog_twopass.hpp.
+// the parity tests compare against; l = 17…97 runs dog_roll.hpp, longer kernels dog_twopass.hpp.
 //
 // Replaces, for a batch of independent search windows, the body of the
 // reference functor /root/reference/src/PawsomeTracker.jl:55-62:

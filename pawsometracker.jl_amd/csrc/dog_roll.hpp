@@ -36,7 +36,10 @@ constexpr int ROLL_CH = 8;   // rows per sub-chunk (16 measured equal on cfg3: t
 constexpr int ROLL_P = 8;    // row-pass outputs per lane
 constexpr int ROLL_TW = 64;  // strip width = lanes
 constexpr int ROLL_PR = 65;  // R pitch (f2)
-constexpr int ROLL_LMIN = 17, ROLL_LMAX = 77; // kernel lengths with a roll instance (l = 4m+1)
+constexpr int ROLL_LMIN = 17, ROLL_LMAX = 97; // kernel lengths with a roll instance (l = 4m+1).  Up to 97 the l + 7 accumulators and the
+                                              // row-pass windows fit 256 VGPRs (2 waves per SIMD) with at most a few spills.  l = 101 / 105
+                                              // spill 25–70 VGPRs: still 1.25–1.3× the two-pass path in batches, but the persistent chain
+                                              // instance for l = 105 returned wrong rows (batch instance correct) — not shipped
 
 // accumulator slots: the l outputs in flight plus the sub-chunk being emitted, rounded so that the
 // slot ↔ tap mapping repeats after a whole number of sub-chunks
@@ -369,7 +372,7 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
                 if (slot & 1) acc2[slot / 2].y = 0.f; else acc2[slot / 2].x = 0.f;
             }
         };
-        static_assert(NBODY <= 11, "extend the phase switch");
+        static_assert(NBODY <= 16, "extend the phase switch");
         switch (phase) {
         case 0: emit(std::integral_constant<int, 0>{}); break;
         case 1: emit(std::integral_constant<int, 1 % NBODY>{}); break;
@@ -381,7 +384,12 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
         case 7: emit(std::integral_constant<int, 7 % NBODY>{}); break;
         case 8: emit(std::integral_constant<int, 8 % NBODY>{}); break;
         case 9: emit(std::integral_constant<int, 9 % NBODY>{}); break;
-        default: emit(std::integral_constant<int, 10 % NBODY>{}); break;
+        case 10: emit(std::integral_constant<int, 10 % NBODY>{}); break;
+        case 11: emit(std::integral_constant<int, 11 % NBODY>{}); break;
+        case 12: emit(std::integral_constant<int, 12 % NBODY>{}); break;
+        case 13: emit(std::integral_constant<int, 13 % NBODY>{}); break;
+        case 14: emit(std::integral_constant<int, 14 % NBODY>{}); break;
+        default: emit(std::integral_constant<int, 15 % NBODY>{}); break;
         }
         __builtin_amdgcn_wave_barrier(); // A / Rb are rewritten by the next sub-chunk
     }

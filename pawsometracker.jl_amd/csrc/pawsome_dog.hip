@@ -113,11 +113,12 @@ const Variant kVariants[] = {
     PDOG_VARIANT(12, 8, 8, 16, 32, 65, 256),
     PDOG_VARIANT(13, 8, 8, 8, 32, 65, 256),
     PDOG_VARIANT(14, 11, 8, 8, 32, 65, 256),
-    // rolling-accumulator kernel: one instance per kernel length l = 4m+1, 17 … 77 (target_width ≈ 5 … 30)
+    // rolling-accumulator kernel: one instance per kernel length l = 4m+1, 17 … 97 (target_width ≈ 5 … 39); id = 100 + l, l = 65 → 100
     PDOG_ROLL_VARIANT(117, 17), PDOG_ROLL_VARIANT(121, 21), PDOG_ROLL_VARIANT(125, 25), PDOG_ROLL_VARIANT(129, 29),
     PDOG_ROLL_VARIANT(133, 33), PDOG_ROLL_VARIANT(137, 37), PDOG_ROLL_VARIANT(141, 41), PDOG_ROLL_VARIANT(145, 45),
     PDOG_ROLL_VARIANT(149, 49), PDOG_ROLL_VARIANT(153, 53), PDOG_ROLL_VARIANT(157, 57), PDOG_ROLL_VARIANT(161, 61),
     PDOG_ROLL_VARIANT(100, 65), PDOG_ROLL_VARIANT(169, 69), PDOG_ROLL_VARIANT(173, 73), PDOG_ROLL_VARIANT(177, 77),
+    PDOG_ROLL_VARIANT(181, 81), PDOG_ROLL_VARIANT(185, 85), PDOG_ROLL_VARIANT(189, 89), PDOG_ROLL_VARIANT(193, 93), PDOG_ROLL_VARIANT(197, 97),
     // any l: two launches with the intermediate in HBM (long kernels, target_width ≳ 40)
     Variant { 200, 13, 16, 16, 16, 0, 256, nullptr, nullptr, false, nullptr, nullptr, 16 },
     // any l, windows whose padded tile fits in LDS: one workgroup per window, one launch (latency path)
@@ -218,11 +219,11 @@ int choose_variant(pdog_tracker *t, int forced)
         }
         if (v.LT != 0 && v.LT != t->L) continue;
         if (v.lds(t->L) > kMaxLds) continue;
-        if (forced < 0 && t->L >= 80 && !v.twopass) continue; // long kernels: two-pass path (measured 1.7× the ring kernel at l = 293)
+        if (forced < 0 && t->L > ROLL_LMAX && !v.twopass) continue; // long kernels: two-pass path (measured 1.7× the ring kernel at l = 293)
         if (v.twopass) {
             const size_t hl = (size_t)HP_ROWS * twopass_pitch(t->n1, t->L) * sizeof(f2);
             if (hl > kMaxLds - 1024) continue;
-            if (forced < 0 && t->L < 80) continue; // the ring/roll kernels win for short kernels
+            if (forced < 0 && t->L <= ROLL_LMAX) continue; // the ring/roll kernels win where a roll instance exists
             if (!best || forced >= 0) { best = &v; best_cost = 0.0; }
             continue;
         }

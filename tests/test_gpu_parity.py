@@ -315,7 +315,7 @@ def test_persistent_multi_clip_chains(pt, oracle):
         for pin in (False, True, 300):
             bt = pt.BatchTracker(h, w, tw, ws, True, fill)
             if pin is True:
-                if bt.info().variant < 100 or bt.info().variant >= 200:
+                if bt.info().variant < 100 or bt.info().variant == 200:
                     bt.close()
                     continue      # no roll instance (hence no persistent kernel) for this kernel length
                 bt.set_variant(bt.info().variant)
@@ -863,4 +863,55 @@ def test_power_of_two_contrast_scales_the_response_exactly(pt):
         p2, r2 = bt.detect(torch.from_numpy(doubled).cuda(), torch.from_numpy(guesses).cuda(), want_resp=True)
         assert torch.equal(p1, p2), variant
         assert torch.equal(r2, 2 * r1), variant
+        bt.close()
+
+
+def _tw_for_kernel_len(oracle, l):
+    for tw10 in range(20, 600):
+        if oracle.kernel_len(oracle.sigma(tw10 / 10)) == l:
+            return tw10 / 10
+    raise AssertionError(l)
+
+
+@pytest.mark.parametrize("l", list(range(17, 98, 4)))
+def test_every_roll_instance_pinned(pt, oracle, l):
+    """One compiled roll-kernel instance per kernel length l = 17, 21, … 97 (dog_roll.hpp).  Small batches are
+    switched to the fused / two-pass kernels at launch, so the instance is pinned here (pdog_set_variant) and run on
+    window shapes that cover a partial strip, an overlapping last strip and remainder columns for the thin kernel —
+    positions and the dense response against the oracle, plus the persistent chain kernel of the same instance."""
+    import torch
+    from oracle import synth
+    from oracle.dog_oracle import OracleTracker
+    tw = _tw_for_kernel_len(oracle, l)
+    rng = np.random.default_rng(1000 + l)
+    K = oracle.dog_kernel(oracle.sigma(tw), True)
+    for ws in ((33, 41), (27, 100), (45, 131), (21, 193)):        # 41: partial strip, 100: overlapping last strip, 131/193: 64k + 3 / + 1
+        radii = (ws[0] // 2, ws[1] // 2)
+        n, h, w = 6, 150, 260
+        frames, guesses, _ = synth.make_batch(n, h, w, max(2, int(tw)), radii, True, seed=int(rng.integers(1 << 30)), noise=3)
+        fill = oracle.mode_u8(frames[0])
+        bt = pt.BatchTracker(h, w, tw, ws, True, fill)
+        vid = bt.info().variant
+        assert vid == (100 if l == 65 else 100 + l) and bt.info().kernel_len == l
+        bt.set_variant(vid)
+        assert bt.kernel_for_batch(n) == vid
+        got, resp = bt.detect(torch.from_numpy(frames).cuda(), torch.from_numpy(guesses).cuda(), want_resp=True)
+        got, resp = got.cpu().numpy(), resp.cpu().numpy()
+        for b in range(n):
+            ij, r = oracle.detect(frames[b], fill, K, radii, guesses[b], want_resp=True)
+            assert tuple(int(v) for v in got[b]) == ij, (l, ws, b)
+            if b < 2:
+                _check_resp(resp[b].T, r, f"roll l={l} {ws} {b}")
+        if ws == (45, 131):      # the persistent chain kernel of this instance: 2 clips x 5 frames
+            clip = np.stack([frames[:5], frames[1:6]])
+            starts = [(int(guesses[0, 0]), int(guesses[0, 1])), (int(guesses[1, 0]), int(guesses[1, 1]))]
+            out = bt.detect_chains(torch.from_numpy(clip).cuda(), torch.tensor(starts, dtype=torch.int32).cuda()).cpu().numpy()
+            for c in range(2):
+                ot = OracleTracker(clip[c][0], tw, ws, True, oracle)
+                ot.fill = fill
+                g = starts[c]
+                for k in range(5):
+                    ot.data[...] = clip[c][k]
+                    g = ot(g)
+                    assert tuple(int(v) for v in out[c][k]) == g, (l, c, k)
         bt.close()
