@@ -902,7 +902,7 @@ def test_every_roll_instance_pinned(pt, oracle, l):
             assert tuple(int(v) for v in got[b]) == ij, (l, ws, b)
             if b < 2:
                 _check_resp(resp[b].T, r, f"roll l={l} {ws} {b}")
-        if ws == (45, 131):      # the persistent chain kernel of this instance: 2 clips x 5 frames
+        if ws != (33, 41):       # the persistent chain kernel of this instance (2, 3 and 4 strip-waves per clip): 2 clips x 5 frames
             clip = np.stack([frames[:5], frames[1:6]])
             starts = [(int(guesses[0, 0]), int(guesses[0, 1])), (int(guesses[1, 0]), int(guesses[1, 1]))]
             out = bt.detect_chains(torch.from_numpy(clip).cuda(), torch.tensor(starts, dtype=torch.int32).cuda()).cpu().numpy()
