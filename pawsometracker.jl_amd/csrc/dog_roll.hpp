@@ -39,7 +39,8 @@ constexpr int ROLL_PR = 65;  // R pitch (f2)
 constexpr int ROLL_LMIN = 17, ROLL_LMAX = 97; // kernel lengths with a roll instance (l = 4m+1).  Up to 97 the l + 7 accumulators and the
                                               // row-pass windows fit 256 VGPRs (2 waves per SIMD) with at most a few spills.  l = 101 / 105
                                               // spill 25–70 VGPRs: still 1.25–1.3× the two-pass path in batches, but the persistent chain
-                                              // instance for l = 105 returned wrong rows (batch instance correct) — not shipped
+                                              // instance for l = 105 returned wrong rows (batch instance correct; not an LDS overrun: the same
+                                              // with 1 KB of LDS padding around every wave) — not shipped
 
 // accumulator slots: the l outputs in flight plus the sub-chunk being emitted, rounded so that the
 // slot ↔ tap mapping repeats after a whole number of sub-chunks
