@@ -69,16 +69,20 @@ def make_frames(torch, n, h, w, tw, radii, seed, noise, device):
 
 
 def stored_traffic(workload, variant, batch):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic_r01.json);
-    None when no counter run exists for this workload/variant/batch (counters cannot be read from inside a
-    timed run: rocprofv3 wraps the process)."""
+    """HBM bytes per STEP (every kernel a step launches, summed) from the committed PMC passes
+    (profiles/traffic_r02.json, written by tools/traffic_from_pmc.py from separate FETCH_SIZE / WRITE_SIZE runs);
+    None when no counter run exists for this workload/variant/batch (counters cannot be read from inside a timed
+    run: rocprofv3 wraps the process)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "traffic_r02.json")) as f:
             rec = json.load(f).get(workload)
         if not rec or rec["variant"] != variant or rec["batch"] != batch:
             return None
-        return int((rec["fetch_size_kib"] * rec["fetch_correction"] + rec["write_size_kib"]) * 1024)
-    except (OSError, KeyError, ValueError):
+        total = 0.0
+        for k in rec["kernels"].values():
+            total += (k["fetch_size_kib"] * k["fetch_correction"] + k["write_size_kib"]) * k["launches_per_step"]
+        return int(total * 1024)
+    except (OSError, KeyError, ValueError, TypeError):
         return None
 
 
@@ -106,7 +110,10 @@ def cpu_baseline(frames_host, guesses_host, fill, tw, radii, budget_s=8.0):
     strict = Oracle(fast=False)
     sig = strict.sigma(tw)
     K = strict.dog_kernel(sig, True)
-    cores = o.max_threads()
+    # threads = what the box will actually schedule: the cgroup CPU quota when there is one (128 OpenMP threads
+    # under a 16-CPU quota mostly measure oversubscription), else every host thread
+    quota = cpu_quota()
+    cores = max(1, min(o.max_threads(), int(quota))) if quota else o.max_threads()
     n_avail = len(frames_host)
 
     def timed_chunks(fn, chunk):
@@ -121,20 +128,20 @@ def cpu_baseline(frames_host, guesses_host, fill, tw, radii, budget_s=8.0):
 
     o.detect(frames_host[0], fill, K, radii, guesses_host[0])          # warm threads/caches
     within, n_w, pos_w = timed_chunks(
-        lambda lo, hi: np.array([o.detect(frames_host[b], fill, K, radii, guesses_host[b]) for b in range(lo, hi)], np.int32), 4)
+        lambda lo, hi: np.array([o.detect(frames_host[b], fill, K, radii, guesses_host[b], nthreads=cores) for b in range(lo, hi)], np.int32), 4)
     across, n_a, pos_a = timed_chunks(
-        lambda lo, hi: o.detect_batch_par(frames_host[lo:hi], fill, K, sig, True, radii, guesses_host[lo:hi], False), cores)
+        lambda lo, hi: o.detect_batch_par(frames_host[lo:hi], fill, K, sig, True, radii, guesses_host[lo:hi], False, nthreads=cores), cores)
     sep, n_s, pos_s = timed_chunks(
-        lambda lo, hi: o.detect_batch_par(frames_host[lo:hi], fill, K, sig, True, radii, guesses_host[lo:hi], True), cores)
+        lambda lo, hi: o.detect_batch_par(frames_host[lo:hi], fill, K, sig, True, radii, guesses_host[lo:hi], True, nthreads=cores), cores)
     m = min(n_w, n_a)
     assert np.array_equal(pos_w[:m], pos_a[:m]) and np.array_equal(pos_s[:min(n_s, n_a)], pos_a[:min(n_s, n_a)]), \
         "oracle: threading modes / separable statement disagree on the sample"
     pos = pos_a if n_a >= n_w else pos_w
-    return {"value": max(within, across), "cores": cores, "pos": pos,
+    return {"value": max(within, across), "cores": cores, "host_threads": o.max_threads(), "pos": pos,
             "within": (within, n_w), "across": (across, n_a), "separable": (sep, n_s)}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -145,21 +152,163 @@ def main():
     ap.add_argument("--variant", type=int, default=-1, help="force a kernel specialisation")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--data-rank", type=int, default=-1, help="generate the synthetic data of this rank (checks the per-rank seeds on one GPU)")
-    args = ap.parse_args()
+    ap.add_argument("--group", action="store_true",
+                    help="N GPUs from ONE process through the C ABI's pdog_group_* (in-process RCCL ncclGather) instead of one process per GPU")
+    return ap.parse_args()
 
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: start the N ranks ourselves, exactly as the driver
+    would (torch.distributed.run, one process per GPU, RCCL), as a CHILD process started before this process has
+    touched the GPU; relay rank 0's JSON line and the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run(cmd, env=env)
+    return p.returncode
+
+
+def tracking_sanity(np, got, centres, guesses_h, fh, fw, tw, radii, noise):
+    """A disc fully inside frame+window must be found within 1 px of its centre (exactly, when noise-free) — a
+    wrong-but-fast kernel must not produce a number."""
+    rad = tw // 2 + 1
+    inside = ((centres[:, 0] > rad) & (centres[:, 0] <= fh - rad) & (centres[:, 1] > rad) & (centres[:, 1] <= fw - rad)
+              & (np.abs(centres - guesses_h) <= np.array(radii) - rad).all(1))
+    err = np.abs(got[inside] - centres[inside]).max() if inside.any() else 0
+    if not os.environ.get("PDOG_BENCH_NOCHECK"):   # timing-only ablation builds produce wrong positions
+        assert err <= (1 if noise else 0), f"tracking sanity failed: max |pos - centre| = {err}"
+
+
+def result_line(args, desc, world, dt, kern_ms, batch, info, kernel_for_batch, fh, fw, tw, sharding):
+    n_total = batch * world
+    value = n_total * args.steps / dt
+    abytes = int(info.algorithmic_bytes_per_window)
+    afma = int(info.algorithmic_fma_per_window)
+    ach_gbs = abytes * batch / (kern_ms * 1e-3) / 1e9
+    fma_rate = afma * batch / (kern_ms * 1e-3)
+    return {
+        "metric": "DoG+argmax frames/s, 1080p 256x256 windows batch 4096; % HBM roofline @1/8 GPU",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {desc}", "frame": [fh, fw], "window": [info.win_h, info.win_w],
+                   "batch_per_gpu": batch, "target_width": tw, "kernel_len": info.kernel_len,
+                   "noise_levels": args.noise, "variant": info.variant, "kernel_for_this_batch": kernel_for_batch,
+                   "strips": info.n_strips, "sharding": sharding},
+        "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach_gbs / HBM_PEAK_GBS, "traffic": stored_traffic(args.workload, info.variant, batch),
+                     "kernel_ms": kern_ms, "algorithmic_bytes_per_window": abytes,
+                     # what `frac` would be with the FP32 vector ALUs 100 % busy on algorithmic FMAs: the ceiling of this path
+                     "frac_at_fp32_vector_peak": abytes / (afma / VALU_PEAK_FMA) / 1e9 / HBM_PEAK_GBS,
+                     "valu": {"achieved_fma_per_s": fma_rate, "peak_fma_per_s": VALU_PEAK_FMA,
+                              "frac": fma_rate / VALU_PEAK_FMA, "algorithmic_fma_per_window": afma},
+                     "note": "path is FP32-VALU bound (375 flop/B vs ridge 19.7, DESIGN.md); achieved = algorithmic bytes of one "
+                             "step / the step's kernel time (HIP events on the launch stream: every kernel of the step); "
+                             "traffic = FETCH_SIZE (x2 gfx950 correction where the kernel reads 16 B/lane) + WRITE_SIZE of every "
+                             "kernel of a step, profiles/traffic_r02.json; the chip sustains ~2.0 GHz under this kernel, "
+                             "valu.peak is quoted at the nominal 2.4 GHz"},
+    }
+
+
+def run_group(args):
+    """N GPUs from one process: pdog_group_* (one tracker + stream per device, contiguous shards, one in-process RCCL
+    ncclGather of the positions to device 0 per step).  Weak scaling like the multi-process path: `batch` windows per GPU."""
     import numpy as np
     import torch
+    import pawsometracker_jl_amd as pt
+    world = args.gpus
+    fh, fw, tw, ws, batch, desc = WORKLOADS[args.workload]
+    if args.batch:
+        batch = args.batch
+    ws = pt.fix_window_size(ws if not isinstance(ws, tuple) else (ws[1], ws[0]))
+    radii = (ws[0] // 2, ws[1] // 2)
+    n_total = batch * world
+    frames, guesses, guesses_h, centres = [], [], [], []
+    fill = 128
+    for r in range(world):
+        dev = torch.device("cuda", r)
+        f, g_h, c = make_frames(torch, batch, fh, fw, tw, radii, seed=1000 * r, noise=args.noise, device=dev)
+        if r == 0 and args.noise:
+            fill = pt.mode(f[0].cpu().numpy())
+        frames.append(f)
+        guesses.append(torch.from_numpy(g_h).to(dev))
+        guesses_h.append(g_h)
+        centres.append(c)
+    gt = pt.GroupTracker(list(range(world)), fh, fw, tw, ws, True, fill)
+    assert all(gt.shard(n_total, r) == (r * batch, (r + 1) * batch) for r in range(world))
+    gt.reserve(n_total)
+    info = gt.info(0)
+    out = torch.empty((n_total, 2), dtype=torch.int32, device="cuda:0")
+    # the trackers launch on their own streams; the kernel time of a step is taken with HIP events on rank 0's
+    root_stream = torch.cuda.ExternalStream(gt.stream(0), device=0)
+    for r in range(world):
+        torch.cuda.synchronize(r)
+    for _ in range(args.warmup):
+        gt.detect(frames, guesses, n_total, out)
+    gt.sync()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for r in range(world):
+        torch.cuda.synchronize(r)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(root_stream)
+        gt.detect(frames, guesses, n_total, out)
+        ev[k][1].record(root_stream)
+    gt.sync()
+    for r in range(world):
+        torch.cuda.synchronize(r)
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    got = out.cpu().numpy()
+    tracking_sanity(np, got, np.concatenate(centres), np.concatenate(guesses_h), fh, fw, tw, radii, args.noise)
+    res = result_line(args, desc, world, dt, kern_ms, batch, info, gt.kernel_for_batch(batch), fh, fw, tw,
+                      f"frames x{world} from one process (pdog_group_*), in-process RCCL ncclGather of int32[n,2] to device 0")
+    res["roofline"]["note"] += "; group mode: kernel_ms = rank 0's kernels + its part of the gather"
+    print(json.dumps(res))
+    gt.close()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    env_world = os.environ.get("WORLD_SIZE")
+    import torch   # device_count() does not initialise the GPU on this image (safe before starting child processes)
+    backend = os.environ.get("PDOG_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible on this node "
+              "(RCCL needs one device per rank; PDOG_BENCH_BACKEND=gloo rehearses the control flow on fewer)", file=sys.stderr)
+        return 2
+    if args.group:
+        if env_world not in (None, "1"):
+            print("bench.py: --group drives every GPU from ONE process; do not start it under torch.distributed.run", file=sys.stderr)
+            return 2
+        return run_group(args)
+    if env_world is None and args.gpus > 1:
+        return self_launch(args)
+    if env_world is not None and int(env_world) != args.gpus:
+        print(f"bench.py: WORLD_SIZE={env_world} but --gpus {args.gpus}: start N ranks for --gpus N "
+              "(or run plain `python bench.py --gpus N`, which starts them itself)", file=sys.stderr)
+        return 2
+
+    import numpy as np
     import torch.distributed as dist
     import pawsometracker_jl_amd as pt
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
     # PDOG_BENCH_BACKEND=gloo rehearses the N > 1 control flow where RCCL cannot run (several ranks on ONE GPU of a
     # development box): ranks then share devices round-robin and the gather goes through host memory
-    backend = os.environ.get("PDOG_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, have)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -224,43 +373,15 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # HIP events on the launch stream
 
     got = out.cpu().numpy()
-    # sanity inside the bench: a disc fully inside frame+window must be found within 1 px of its
-    # centre (exactly, when noise-free) — a wrong-but-fast kernel must not produce a number
-    rad = tw // 2 + 1
-    inside = ((centres[:, 0] > rad) & (centres[:, 0] <= fh - rad) & (centres[:, 1] > rad) & (centres[:, 1] <= fw - rad)
-              & (np.abs(centres - guesses_h) <= np.array(radii) - rad).all(1))
-    err = np.abs(got[inside] - centres[inside]).max() if inside.any() else 0
-    if not os.environ.get("PDOG_BENCH_NOCHECK"):   # timing-only ablation builds produce wrong positions
-        assert err <= (1 if args.noise else 0), f"tracking sanity failed: max |pos - centre| = {err}"
+    tracking_sanity(np, got, centres, guesses_h, fh, fw, tw, radii, args.noise)
+    if world > 1 and rank == 0:   # the gathered list is the shards in rank order: rank 0's block must be its own answers
+        g0 = gathered.cpu().numpy()
+        assert g0.shape == (n_total, 2) and np.array_equal(g0[:batch], got), "gathered positions: rank 0's shard differs from its own results"
 
     if rank == 0:
-        value = n_total * args.steps / dt
-        abytes = int(info.algorithmic_bytes_per_window)
-        afma = int(info.algorithmic_fma_per_window)
-        ach_gbs = abytes * batch / (kern_ms * 1e-3) / 1e9
-        fma_rate = afma * batch / (kern_ms * 1e-3)
-        res = {
-            "metric": "DoG+argmax frames/s, 1080p 256x256 windows batch 4096; % HBM roofline @1/8 GPU",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "frame": [fh, fw], "window": [info.win_h, info.win_w],
-                       "batch_per_gpu": batch, "target_width": tw, "kernel_len": info.kernel_len,
-                       "noise_levels": args.noise, "variant": info.variant, "kernel_for_this_batch": bt.kernel_for_batch(batch),
-                       "strips": info.n_strips,
-                       "sharding": (f"frames x{world}, gather int32[n,2] to rank 0" + ("" if backend == "nccl" else f" ({backend} rehearsal)"))
-                                   if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": stored_traffic(args.workload, info.variant, batch),
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_window": abytes,
-                         # what `frac` would be with the FP32 vector ALUs 100 % busy on algorithmic FMAs: the ceiling of this path
-                         "frac_at_fp32_vector_peak": abytes / (afma / VALU_PEAK_FMA) / 1e9 / HBM_PEAK_GBS,
-                         "valu": {"achieved_fma_per_s": fma_rate, "peak_fma_per_s": VALU_PEAK_FMA,
-                                  "frac": fma_rate / VALU_PEAK_FMA, "algorithmic_fma_per_window": afma},
-                         "note": "path is FP32-VALU bound (375 flop/B vs ridge 19.7, DESIGN.md); traffic = FETCH_SIZE x2 (gfx950 "
-                                 "16 B/lane correction) + WRITE_SIZE from profiles/traffic_r01.json, bytes per launch; the chip "
-                                 "sustains ~2.0 GHz under this kernel, valu.peak is quoted at the nominal 2.4 GHz"},
-        }
+        sharding = (f"frames x{world}, one process per GPU, gather int32[n,2] to rank 0" + ("" if backend == "nccl" else f" ({backend} rehearsal)")) \
+            if world > 1 else "single GPU"
+        res = result_line(args, desc, world, dt, kern_ms, batch, info, bt.kernel_for_batch(batch), fh, fw, tw, sharding)
         if world == 1 and not args.no_cpu:
             ns = min(256, batch)
             cb = cpu_baseline(frames[:ns].cpu().numpy(), guesses_h[:ns], fill, tw, radii)
@@ -268,10 +389,11 @@ def main():
             assert np.array_equal(cpos, got[:len(cpos)]), "GPU positions differ from the CPU oracle on the sample"
             L = info.kernel_len
             res["cpu_baseline"] = {
-                "value": cb["value"], "unit": "frames/s", "cores": cb["cores"], "cgroup_cpu_quota": cpu_quota(), "kind": "port",
+                "value": cb["value"], "unit": "frames/s", "cores": cb["cores"], "effective_cores": cb["cores"],
+                "host_threads_visible": cb["host_threads"], "cgroup_cpu_quota": cpu_quota(), "kind": "port",
                 "sample": f"first {cb['across'][1]} windows of the same batch (time-bounded), dense {L}x{L} Float64 correlation + "
-                          "first-max argmax (oracle/dog_oracle.c, -Ofast, OpenMP); value = the faster of the two threadings; "
-                          f"positions equal to the GPU's on all {len(cpos)} sampled windows",
+                          "first-max argmax (oracle/dog_oracle.c, -Ofast, OpenMP, threads = the cgroup CPU quota); value = the "
+                          f"faster of the two threadings; positions equal to the GPU's on all {len(cpos)} sampled windows",
                 "threads_across_windows": {"value": cb["across"][0], "windows": cb["across"][1],
                                            "note": "one window per core, each window single-threaded"},
                 "threads_within_window": {"value": cb["within"][0], "windows": cb["within"][1],
@@ -283,7 +405,8 @@ def main():
     bt.close()
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -98,6 +98,8 @@ int pdog_set_fill(pdog_tracker *t, int fill);
 /* Launch on this hipStream_t instead of the tracker's own stream (NULL = HIP's null stream,
  * which is what torch.cuda.current_stream().cuda_stream reports for torch's default stream). */
 int pdog_set_stream(pdog_tracker *t, void *hip_stream);
+/* The hipStream_t the tracker launches on right now (its own stream unless pdog_set_stream changed it). */
+int pdog_get_stream(const pdog_tracker *t, void **out_hip_stream);
 /* Pre-size the per-window workspace so pdog_detect_batch never allocates. */
 int pdog_reserve(pdog_tracker *t, int max_windows);
 /* The kernel family a batch of n windows would run on (variant id: 300 = one workgroup per window,
@@ -174,6 +176,46 @@ int pdog_free_host(void *p);
 int pdog_detect_chain_progress(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
                                int64_t row_stride, int n_frames, const int32_t start_guess[2],
                                int32_t *h_out_ij, int32_t *h_progress);
+
+/* ---- several GPUs of one node behind one handle ----
+ * The functor is applied to n independent windows (src/PawsomeTracker.jl:55-62, "N independent
+ * applications"), so a batch shards by contiguous window ranges: rank r of the group owns windows
+ * [lo_r, hi_r) (pdog_group_shard; sizes differ by at most one), keeps ITS frames and guesses resident on
+ * ITS device, and runs pdog_detect_batch there.  The only exchange is the result: one ncclGather (RCCL over
+ * xGMI) of the int32 (row, col) pairs to the root device — the positions `track` returns as
+ * CartesianIndex.(indices), src/PawsomeTracker.jl:173.  One host process drives all devices
+ * (ncclCommInitAll); a group of size 1 is valid and runs the same code (RCCL accepts a 1-rank communicator).
+ * A serial chain (src/PawsomeTracker.jl:167) does not shard: use one pdog_tracker per clip and device. */
+typedef struct pdog_group pdog_group;
+
+/* devices: ndev HIP ordinals (NULL = 0 … ndev-1); devices[0] is the root that receives the results.
+ * Other arguments as pdog_create; every rank gets the same Tracker parameters. */
+int pdog_group_create(int ndev, const int *devices, int frame_h, int frame_w, double target_width,
+                      int win_h, int win_w, int darker_target, int fill, pdog_group **out);
+int pdog_group_destroy(pdog_group *g);
+int pdog_group_size(const pdog_group *g);
+/* Borrowed handle of rank's tracker (pdog_get_info, pdog_set_variant, pdog_reserve, pdog_set_stream …);
+ * owned by the group. */
+int pdog_group_tracker(pdog_group *g, int rank, pdog_tracker **out);
+/* The contiguous window range [*lo, *hi) of n_total windows that `rank` owns. */
+int pdog_group_shard(const pdog_group *g, int n_total, int rank, int *lo, int *hi);
+/* The same partition as pure host arithmetic (no group, no GPU): rank's range of n_total windows over ndev
+ * ranks, and its inverse — the rank that owns `window` and the window's index inside that rank's shard (what
+ * the root uses to put the gathered blocks back into window order). */
+int pdog_shard_range(int n_total, int ndev, int rank, int *lo, int *hi);
+int pdog_shard_owner(int n_total, int ndev, int window, int *rank, int *local_index);
+/* n_total independent windows over the group.  Per-rank arrays (host arrays of ndev device pointers, each
+ * pointer valid on that rank's device):
+ *   d_frames[r]       rank r's frames (frame k at + k*frame_stride), n_frames[r] of them
+ *   d_frame_index[r]  NULL, or hi_r - lo_r int32: shard-local window b looks at frame d_frame_index[r][b];
+ *                     the array of pointers itself may be NULL
+ *   d_guesses[r]      (hi_r - lo_r) x 2 int32, 1-based (row, col): the guesses of windows lo_r … hi_r-1
+ * d_out_ij: n_total x 2 int32 on the ROOT device, window order.  Asynchronous: every rank's kernels run on its
+ * tracker's stream, the gather is enqueued behind them; pdog_group_sync waits for all of it. */
+int pdog_group_detect_batch(pdog_group *g, const uint8_t *const *d_frames, int64_t frame_stride,
+                            int64_t row_stride, const int *n_frames, const int32_t *const *d_frame_index,
+                            const int32_t *const *d_guesses, int n_total, int32_t *d_out_ij);
+int pdog_group_sync(pdog_group *g);
 
 #ifdef __cplusplus
 }

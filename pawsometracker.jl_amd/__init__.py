@@ -6,4 +6,4 @@ as `pawsometracker_jl_amd` (the loader stub at the repo root registers it).
 from ._lib import LIB_PATH, PdogError, lib  # noqa: F401
 from .tracker import (Tracker, fix_window_size, get_guess, get_sigma,  # noqa: F401
                       get_start_ij_and_tracker, guess_window_size, mode, track_frames)
-from .batch import BatchTracker, gather_positions, mode_device, shard_range  # noqa: F401
+from .batch import BatchTracker, GroupTracker, gather_positions, mode_device, shard_range  # noqa: F401

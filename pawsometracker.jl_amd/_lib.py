@@ -18,7 +18,9 @@ SYMBOLS = (
     "pdog_gaussian_taps", "pdog_mode_u8", "pdog_mode_u8_device", "pdog_create", "pdog_destroy", "pdog_get_info",
     "pdog_set_fill", "pdog_set_stream", "pdog_reserve", "pdog_set_variant", "pdog_kernel_for_batch", "pdog_sync",
     "pdog_detect_batch", "pdog_detect_host", "pdog_window_tile", "pdog_detect_batch_host", "pdog_detect_chain", "pdog_detect_chains",
-    "pdog_alloc_host", "pdog_free_host", "pdog_detect_chain_progress",
+    "pdog_alloc_host", "pdog_free_host", "pdog_detect_chain_progress", "pdog_get_stream",
+    "pdog_group_create", "pdog_group_destroy", "pdog_group_size", "pdog_group_tracker", "pdog_group_shard",
+    "pdog_group_detect_batch", "pdog_group_sync", "pdog_shard_range", "pdog_shard_owner",
 )
 
 
@@ -60,7 +62,8 @@ def _preload_torch_hip_runtime():
     if not spec or not spec.origin:
         return
     libdir = os.path.join(os.path.dirname(spec.origin), "lib")
-    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+    # librccl too: the library links RCCL for pdog_group_*, and torch ships its own copy (SONAME librccl.so.1)
+    for name in ("libhsa-runtime64.so", "libamdhip64.so", "librccl.so"):
         path = os.path.join(libdir, name)
         if os.path.exists(path):
             try:
@@ -114,6 +117,17 @@ def lib():
         L.pdog_detect_chain_progress.restype = i; L.pdog_detect_chain_progress.argtypes = [p, p, i64, i64, i, p, p, p]
     if hasattr(L, "pdog_detect_chains"):  # absent only in older A/B builds selected through PAWSOME_DOG_LIB
         L.pdog_detect_chains.restype = i; L.pdog_detect_chains.argtypes = [p, p, i64, i64, i, i, p, p]
+    if hasattr(L, "pdog_group_create"):
+        L.pdog_get_stream.restype = i; L.pdog_get_stream.argtypes = [p, C.POINTER(p)]
+        L.pdog_group_create.restype = i; L.pdog_group_create.argtypes = [i, p, i, i, d, i, i, i, i, C.POINTER(p)]
+        L.pdog_group_destroy.restype = i; L.pdog_group_destroy.argtypes = [p]
+        L.pdog_group_size.restype = i; L.pdog_group_size.argtypes = [p]
+        L.pdog_group_tracker.restype = i; L.pdog_group_tracker.argtypes = [p, i, C.POINTER(p)]
+        L.pdog_group_shard.restype = i; L.pdog_group_shard.argtypes = [p, i, i, C.POINTER(i), C.POINTER(i)]
+        L.pdog_group_detect_batch.restype = i; L.pdog_group_detect_batch.argtypes = [p, p, i64, i64, p, p, p, i, p]
+        L.pdog_group_sync.restype = i; L.pdog_group_sync.argtypes = [p]
+        L.pdog_shard_range.restype = i; L.pdog_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
+        L.pdog_shard_owner.restype = i; L.pdog_shard_owner.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
     _lib = L
     return L
 

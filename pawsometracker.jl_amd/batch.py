@@ -117,8 +117,12 @@ class BatchTracker:
         assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3 and frames.stride(2) == 1
         cp = ChainProgress(self, frames.shape[0], frames)
         g = (C.c_int32 * 2)(int(start_guess[0]), int(start_guess[1]))
-        _lib.check(_lib.lib().pdog_detect_chain_progress(self._h, C.c_void_p(frames.data_ptr()), frames.stride(0), frames.stride(1),
-                                                         frames.shape[0], g, cp._out_ptr, cp._prog_ptr))
+        try:
+            _lib.check(_lib.lib().pdog_detect_chain_progress(self._h, C.c_void_p(frames.data_ptr()), frames.stride(0), frames.stride(1),
+                                                             frames.shape[0], g, cp._out_ptr, cp._prog_ptr))
+        except Exception:
+            cp.close()      # nothing was queued: the pinned buffers go back at once
+            raise
         return cp
 
     def detect_chains(self, frames, start_guesses, out=None):
@@ -155,10 +159,16 @@ class ChainProgress:
     def __init__(self, bt, n_frames, keepalive=None):
         import numpy as np
         self._bt, self.n_frames, self._keepalive = bt, int(n_frames), keepalive
+        self._out_ptr = self._prog_ptr = None
         out, prog = C.c_void_p(), C.c_void_p()
         _lib.check(_lib.lib().pdog_alloc_host(8 * self.n_frames, C.byref(out)))
-        _lib.check(_lib.lib().pdog_alloc_host(4, C.byref(prog)))
-        self._out_ptr, self._prog_ptr = out, prog
+        self._out_ptr = out
+        try:
+            _lib.check(_lib.lib().pdog_alloc_host(4, C.byref(prog)))
+        except Exception:
+            self.close()
+            raise
+        self._prog_ptr = prog
         self.positions = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int32)), shape=(self.n_frames, 2))
         self._prog = np.ctypeslib.as_array(C.cast(prog, C.POINTER(C.c_int32)), shape=(1,))
 
@@ -170,12 +180,118 @@ class ChainProgress:
         return self.positions.copy()
 
     def close(self):
-        if self._out_ptr is not None:
+        """Give the pinned buffers back.  The chain that writes them must have finished: the tracker's stream is
+        drained first — unless the tracker itself is already closed (pdog_destroy drains its stream)."""
+        if self._out_ptr is None and self._prog_ptr is None:
+            return
+        if getattr(self._bt, "_h", None):
             self._bt.sync()
-            self.positions = self._prog = None
-            _lib.lib().pdog_free_host(self._out_ptr)
-            _lib.lib().pdog_free_host(self._prog_ptr)
-            self._out_ptr = self._prog_ptr = None
+        self.positions = self._prog = None
+        for ptr in (self._out_ptr, self._prog_ptr):
+            if ptr is not None:
+                _lib.lib().pdog_free_host(ptr)
+        self._out_ptr = self._prog_ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GroupTracker:
+    """Several GPUs of one node behind one handle (pdog_group_*): contiguous window shards per device, frames and
+    guesses resident on the owning device, one RCCL gather of the int32 positions to the root device per batch
+    (the sharded unit is the functor src/PawsomeTracker.jl:55-62, the gathered result :173).
+    One host process drives every device; torch only provides the device memory."""
+
+    def __init__(self, devices, frame_h, frame_w, target_width, window_size, darker_target, fill):
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().pdog_group_create(len(self.devices), arr, int(frame_h), int(frame_w), float(target_width),
+                                                int(window_size[0]), int(window_size[1]), int(bool(darker_target)),
+                                                int(fill), C.byref(h)))
+        self._h = h
+        self.frame_h, self.frame_w = int(frame_h), int(frame_w)
+
+    def size(self):
+        return _lib.lib().pdog_group_size(self._h)
+
+    def shard(self, n_total, rank):
+        lo, hi = C.c_int(), C.c_int()
+        _lib.check(_lib.lib().pdog_group_shard(self._h, int(n_total), int(rank), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def info(self, rank=0):
+        t = C.c_void_p()
+        _lib.check(_lib.lib().pdog_group_tracker(self._h, int(rank), C.byref(t)))
+        o = _lib.PdogInfo()
+        _lib.check(_lib.lib().pdog_get_info(t, C.byref(o)))
+        return o
+
+    def _tracker(self, rank):
+        t = C.c_void_p()
+        _lib.check(_lib.lib().pdog_group_tracker(self._h, int(rank), C.byref(t)))
+        return t
+
+    def stream(self, rank):
+        """The hipStream_t (as an int) rank's tracker launches on."""
+        st = C.c_void_p()
+        _lib.check(_lib.lib().pdog_get_stream(self._tracker(rank), C.byref(st)))
+        return st.value or 0
+
+    def kernel_for_batch(self, n_per_rank, rank=0):
+        o = C.c_int()
+        _lib.check(_lib.lib().pdog_kernel_for_batch(self._tracker(rank), int(n_per_rank), C.byref(o)))
+        return o.value
+
+    def reserve(self, n_total):
+        for r in range(len(self.devices)):
+            lo, hi = self.shard(n_total, r)
+            t = C.c_void_p()
+            _lib.check(_lib.lib().pdog_group_tracker(self._h, r, C.byref(t)))
+            _lib.check(_lib.lib().pdog_reserve(t, max(1, hi - lo)))
+
+    def detect(self, frames, guesses, n_total, out, frame_index=None):
+        """frames[r]: uint8 cuda tensor [nf_r, h, w] on device r (same strides on every rank); guesses[r]: int32 cuda
+        [n_r, 2] on device r, n_r = the size of rank r's shard of n_total; out: int32 cuda [n_total, 2] on the root
+        device.  Asynchronous (each rank's tracker stream); sync() waits.  The caller keeps the tensors alive until then."""
+        import torch
+        nd = len(self.devices)
+        assert len(frames) == nd and len(guesses) == nd
+        for r in range(nd):
+            f, gq = frames[r], guesses[r]
+            lo, hi = self.shard(n_total, r)
+            assert f.is_cuda and f.dtype == torch.uint8 and f.dim() == 3 and f.stride(2) == 1 and f.device.index == self.devices[r]
+            assert f.shape[1] == self.frame_h and f.shape[2] == self.frame_w
+            assert f.stride(0) == frames[0].stride(0) and f.stride(1) == frames[0].stride(1)
+            assert gq.is_cuda and gq.dtype == torch.int32 and gq.is_contiguous() and gq.shape == (hi - lo, 2) and gq.device.index == self.devices[r]
+        assert out.is_cuda and out.dtype == torch.int32 and out.is_contiguous() and out.shape == (n_total, 2) and out.device.index == self.devices[0]
+        P = C.c_void_p * nd
+        fr = P(*[f.data_ptr() for f in frames])
+        gs = P(*[q.data_ptr() for q in guesses])
+        nf = (C.c_int * nd)(*[f.shape[0] for f in frames])
+        fi = None
+        if frame_index is not None:
+            fi = P(*[(x.data_ptr() if x is not None else None) for x in frame_index])
+        _lib.check(_lib.lib().pdog_group_detect_batch(self._h, fr, frames[0].stride(0), frames[0].stride(1), nf, fi, gs,
+                                                      int(n_total), C.c_void_p(out.data_ptr())))
+        return out
+
+    def sync(self):
+        _lib.check(_lib.lib().pdog_group_sync(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().pdog_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def mode_device(frame):

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
 }
 
 // frames finished so far, for paths whose own kernels do not publish it (see pdog_detect_chain_progress)
-__global__ void dog_publish_kernel(int32_t *flag, int32_t value)
+static __global__ void dog_publish_kernel(int32_t *flag, int32_t value)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(NT, 2) void dog_window_kernel(const LaunchGeo g, co
 
 // Combine the strips of each window, map window-local → absolute, clamp
 // (src/PawsomeTracker.jl:60-61).  One thread per window.
-__global__ void dog_finalize_kernel(const float *__restrict__ part_val, const int *__restrict__ part_idx,
+static __global__ void dog_finalize_kernel(const float *__restrict__ part_val, const int *__restrict__ part_idx,
                                     const int *__restrict__ guesses, int *__restrict__ out_ij,
                                     int n, int nstrips, int r1, int r2, int n1, int fh, int fw)
 {
@@ -393,7 +393,7 @@ __global__ void dog_finalize_kernel(const float *__restrict__ part_val, const in
 // value that ends with the maximum count M reaches M at its LAST occurrence, so the winner is: largest count,
 // ties → the value whose last occurrence comes earliest in column-major order (index j·h + i).  One pass:
 // per-workgroup LDS histogram + last-occurrence table, flushed with atomics; 2 KB go back to the host.
-__global__ __launch_bounds__(256) void dog_mode_kernel(const uint8_t *__restrict__ img, int h, int w, long long row_stride,
+static __global__ __launch_bounds__(256) void dog_mode_kernel(const uint8_t *__restrict__ img, int h, int w, long long row_stride,
                                                        unsigned *__restrict__ hist, unsigned *__restrict__ last)
 {
     __shared__ unsigned shist[256], slast[256];

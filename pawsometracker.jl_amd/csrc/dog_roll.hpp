@@ -485,7 +485,7 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
 
 // Step of a multi-clip chain run as ordinary batches: file the step's answers under [clip][frame] and make
 // them the next step's guesses.
-__global__ void dog_chain_step_kernel(const int *__restrict__ step_ij, int *__restrict__ cur, int *__restrict__ out_ij,
+static __global__ void dog_chain_step_kernel(const int *__restrict__ step_ij, int *__restrict__ cur, int *__restrict__ out_ij,
                                       int n_clips, int n_frames, int k)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

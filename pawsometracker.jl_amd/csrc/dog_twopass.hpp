@@ -43,7 +43,7 @@ struct TwoPassGeo {
     int32_t done_value;          // right after window 0's answer: the host functor polls it (see dog_fused.hpp)
 };
 
-__global__ __launch_bounds__(64) void dog_dc_kernel(const LaunchGeo g, int *__restrict__ dc)
+static __global__ __launch_bounds__(64) void dog_dc_kernel(const LaunchGeo g, int *__restrict__ dc)
 {
     const int b = blockIdx.x, lane = threadIdx.x, hw = g.L >> 1;
     const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];

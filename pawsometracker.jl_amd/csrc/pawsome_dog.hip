@@ -26,6 +26,18 @@
 
 using namespace pdog;
 
+// the roll kernels are instantiated in roll_inst.hip (one translation unit per set of lengths, built in parallel)
+namespace pdog {
+#define PDOG_ROLL_L(LT)                                                                                          \
+    extern template __global__ void dog_roll_kernel<LT, false, 0>(const LaunchGeo, const f2 *, const f2 *);      \
+    extern template __global__ void dog_roll_kernel<LT, true, 0>(const LaunchGeo, const f2 *, const f2 *);       \
+    extern template __global__ void dog_thin_kernel<LT, false>(const LaunchGeo, const f2 *, const f2 *);         \
+    extern template __global__ void dog_thin_kernel<LT, true>(const LaunchGeo, const f2 *, const f2 *);          \
+    extern template __global__ void dog_chain_kernel<LT>(const ChainGeo, const f2 *, const f2 *);
+#include "roll_lengths.def"
+#undef PDOG_ROLL_L
+} // namespace pdog
+
 namespace {
 
 thread_local std::string g_err;
@@ -34,6 +46,41 @@ int fail(int code, const std::string &msg)
 {
     g_err = msg;
     return code;
+}
+
+// Run-time switches (DESIGN.md "Run-time switches"): the environment is read ONCE, when a tracker is created —
+// never on the launch path (a functor call's whole budget is ≈23 µs).
+struct Switches {
+    bool host_copy = false, host_sync = false, host_trace = false, twopass_4l = false, hpass16 = false;
+    bool ingest_no_nt = false, ingest_trace = false, fused_diag = false;
+    size_t scratch_cap = (size_t)6 << 30; // HBM scratch of the two-pass intermediate; larger batches go in chunks
+    int fused_pr = 0, fused_pc = 0;       // PDOG_FUSED_P=pr,pc (0: chosen per geometry)
+    int host_threads = 0;                 // PDOG_HOST_THREADS (0: min(16, cores))
+    int ingest_chunk = 0;                 // PDOG_INGEST_CHUNK (0: ≈32 MB of tiles)
+    int lds_pad = 0;                      // PDOG_LDS_PAD (diagnostic build only)
+};
+Switches read_switches()
+{
+    Switches w;
+    auto on = [](const char *n) { return std::getenv(n) != nullptr; };
+    w.host_copy = on("PDOG_HOST_COPY");
+    w.host_sync = on("PDOG_HOST_SYNC");
+    w.host_trace = on("PDOG_HOST_TRACE");
+    w.twopass_4l = on("PDOG_TWOPASS_4L");
+    w.hpass16 = on("PDOG_HPASS16");
+    w.ingest_no_nt = on("PDOG_INGEST_NO_NT");
+    w.ingest_trace = on("PDOG_INGEST_TRACE");
+    w.fused_diag = on("PDOG_FUSED_DIAG");
+    if (const char *e = std::getenv("PDOG_SCRATCH_MB")) w.scratch_cap = (size_t)std::max(1, std::atoi(e)) << 20;
+    if (const char *e = std::getenv("PDOG_FUSED_P")) {
+        int a = 0, b = 0;
+        if (std::sscanf(e, "%d,%d", &a, &b) == 2 && (a == 3 || a == 4 || a == 5 || a == 6 || a == 8) &&
+            (b == 2 || b == 3 || b == 4 || b == 6 || b == 8)) { w.fused_pr = a; w.fused_pc = b; }
+    }
+    if (const char *e = std::getenv("PDOG_HOST_THREADS")) w.host_threads = std::max(1, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("PDOG_INGEST_CHUNK")) w.ingest_chunk = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("PDOG_LDS_PAD")) w.lds_pad = std::max(0, std::atoi(e));
+    return w;
 }
 
 #define HIP_TRY(expr)                                                                       \
@@ -113,12 +160,10 @@ const Variant kVariants[] = {
     PDOG_VARIANT(12, 8, 8, 16, 32, 65, 256),
     PDOG_VARIANT(13, 8, 8, 8, 32, 65, 256),
     PDOG_VARIANT(14, 11, 8, 8, 32, 65, 256),
-    // rolling-accumulator kernel: one instance per kernel length l = 4m+1, 17 … 97 (target_width ≈ 5 … 39); id = 100 + l, l = 65 → 100
-    PDOG_ROLL_VARIANT(117, 17), PDOG_ROLL_VARIANT(121, 21), PDOG_ROLL_VARIANT(125, 25), PDOG_ROLL_VARIANT(129, 29),
-    PDOG_ROLL_VARIANT(133, 33), PDOG_ROLL_VARIANT(137, 37), PDOG_ROLL_VARIANT(141, 41), PDOG_ROLL_VARIANT(145, 45),
-    PDOG_ROLL_VARIANT(149, 49), PDOG_ROLL_VARIANT(153, 53), PDOG_ROLL_VARIANT(157, 57), PDOG_ROLL_VARIANT(161, 61),
-    PDOG_ROLL_VARIANT(100, 65), PDOG_ROLL_VARIANT(169, 69), PDOG_ROLL_VARIANT(173, 73), PDOG_ROLL_VARIANT(177, 77),
-    PDOG_ROLL_VARIANT(181, 81), PDOG_ROLL_VARIANT(185, 85), PDOG_ROLL_VARIANT(189, 89), PDOG_ROLL_VARIANT(193, 93), PDOG_ROLL_VARIANT(197, 97),
+    // rolling-accumulator kernel: one instance per kernel length l = 4m+1 of roll_lengths.def (target_width ≈ 5 … 39); id = 100 + l, l = 65 → 100
+#define PDOG_ROLL_L(LT) PDOG_ROLL_VARIANT((LT) == 65 ? 100 : 100 + (LT), LT),
+#include "roll_lengths.def"
+#undef PDOG_ROLL_L
     // any l: two launches with the intermediate in HBM (long kernels, target_width ≳ 40)
     Variant { 200, 13, 16, 16, 16, 0, 256, nullptr, nullptr, false, nullptr, nullptr, 16 },
     // any l, windows whose padded tile fits in LDS: one workgroup per window, one launch (latency path)
@@ -149,6 +194,8 @@ const Variant *find_variant(int id)
 
 struct pdog_tracker {
     int device = 0;
+    Switches sw;                   // environment switches as they were when the tracker was created
+    hipEvent_t ev_switch = nullptr; // orders a new stream behind the work queued on the previous one (pdog_set_stream)
     int fh = 0, fw = 0, r1 = 0, r2 = 0, n1 = 0, n2 = 0, L = 0, fill = 0, darker = 0;
     double tw = 0, sigma = 0;
     const Variant *var = nullptr;
@@ -387,11 +434,7 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     };
     fg.pr = pick(fg.NA, t->n2, {3, 4, 5, 6, 8}, 2.0);
     fg.pc = pick(t->n2, t->n1, {2, 3, 4, 6, 8}, 1.5);
-    if (const char *e = std::getenv("PDOG_FUSED_P")) { // tuning switch: "pr,pc"
-        int a = 0, b = 0;
-        if (std::sscanf(e, "%d,%d", &a, &b) == 2 && (a == 3 || a == 4 || a == 5 || a == 6 || a == 8) &&
-            (b == 2 || b == 3 || b == 4 || b == 6 || b == 8)) { fg.pr = a; fg.pc = b; }
-    }
+    if (t->sw.fused_pr) { fg.pr = t->sw.fused_pr; fg.pc = t->sw.fused_pc; } // tuning switch PDOG_FUSED_P
     fg.chain_len = chain_len;
     fg.out_ij = d_out_ij;
     fg.done_flag = d_done_flag;
@@ -401,7 +444,7 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     typedef fused_fn_t fused_fn;
     fused_fn fn = fused_kernel_for(t->L, d_out_resp != nullptr);
 #ifdef PDOG_ABLATIONS
-    if (d_out_resp && std::getenv("PDOG_FUSED_DIAG")) { // phase stamps instead of the response (tools/fused_phases.py)
+    if (d_out_resp && t->sw.fused_diag) { // phase stamps instead of the response (tools/fused_phases.py)
         fn = (fused_fn)dog_fused_kernel<true, 1>;
         if (int rc = raise_lds_limit((const void *)fn, lds)) return rc;
     }
@@ -446,7 +489,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     }
     // small batches: fewer than ≈1000 strip-waves cannot fill 256 CUs × 8 waves; the two-pass kernels can
     if (path == kPathTwoPass) {
-        const int hr = std::getenv("PDOG_HPASS16") ? HP_ROWS : 8; // 8 RT rows per workgroup (32 KB LDS → 4 workgroups per CU): +3 % on cfg5 vs 16; env = tuning switch
+        const int hr = t->sw.hpass16 ? HP_ROWS : 8; // 8 RT rows per workgroup (32 KB LDS → 4 workgroups per CU): +3 % on cfg5 vs 16; env = tuning switch
         const int tp_slots = (t->n2 + hr - 1) / hr; // partial slots = hr-column blocks
         g.nstrips = tp_slots;
         g.nslots = tp_slots;
@@ -460,8 +503,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         tg.pitchA = twopass_pitch(t->n2, t->L);
         tg.pitchV = twopass_pitch(t->n1, t->L, hr);
         const size_t per_win = (size_t)t->n2 * tg.NA * sizeof(f2);
-        size_t cap = (size_t)6 << 30; // HBM scratch for the transposed intermediate; larger batches go in chunks
-        if (const char *e = std::getenv("PDOG_SCRATCH_MB")) cap = (size_t)std::max(1, std::atoi(e)) << 20;
+        const size_t cap = t->sw.scratch_cap; // HBM scratch for the transposed intermediate; larger batches go in chunks
         const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, cap / per_win));
         if (t->v_bytes < per_win * chunk || t->dc_cap < n) {
             HIP_TRY(hipStreamSynchronize(t->stream));
@@ -490,7 +532,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         // the auto-detect pass): launches are what such a batch costs, so the DC level is derived inside the row pass
         // and the last column-pass workgroup of a window combines its partials — two launches instead of four.
         constexpr int kLowLatMax = 16; // measured crossover (257×257 and 271×481 windows): 2 launches win up to 16 windows, 4 launches beyond
-        if (n <= kLowLatMax && n <= chunk && hr == 8 && !std::getenv("PDOG_TWOPASS_4L")) {
+        if (n <= kLowLatMax && n <= chunk && hr == 8 && !t->sw.twopass_4l) {
             if (!t->d_counter) {
                 HIP_TRY(hipMalloc(&t->d_counter, sizeof(int) * kLowLatMax));
                 HIP_TRY(hipMemsetAsync(t->d_counter, 0, sizeof(int) * kLowLatMax, t->stream));
@@ -546,8 +588,8 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     }
     size_t lds_bytes = v.lds(t->L);
 #ifdef PDOG_ABLATIONS
-    if (const char *e = std::getenv("PDOG_LDS_PAD")) { // occupancy experiments: extra LDS per workgroup
-        lds_bytes += (size_t)std::atoi(e);
+    if (t->sw.lds_pad) { // occupancy experiments: extra LDS per workgroup
+        lds_bytes += (size_t)t->sw.lds_pad;
         (void)raise_lds_limit((const void *)(d_out_resp ? v.fn_resp : v.fn), lds_bytes);
     }
 #endif
@@ -563,6 +605,8 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
 }
 
 } // namespace
+
+extern "C" __attribute__((visibility("hidden"))) void pdog_set_error_text(const char *msg) { g_err = msg ? msg : ""; }
 
 extern "C" {
 
@@ -651,6 +695,7 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
 
     pdog_tracker *t = new pdog_tracker();
     t->device = device;
+    t->sw = read_switches();
     t->fh = frame_h; t->fw = frame_w;
     t->tw = target_width;
     t->sigma = sigma_of(target_width);             // :41
@@ -689,6 +734,7 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
     CREATE_TRY(hipStreamCreateWithFlags(&t->aux_stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&t->ev_switch, hipEventDisableTiming));
     CREATE_TRY(hipMalloc(&t->d_taps_row, sizeof(f2) * tr.size()));
     CREATE_TRY(hipMalloc(&t->d_taps_col, sizeof(f2) * tc.size()));
     CREATE_TRY(hipMemcpy(t->d_taps_row, tr.data(), sizeof(f2) * tr.size(), hipMemcpyHostToDevice));
@@ -753,6 +799,7 @@ int pdog_destroy(pdog_tracker *t)
     if (t->aux_stream) { (void)hipStreamSynchronize(t->aux_stream); (void)hipStreamDestroy(t->aux_stream); }
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+    if (t->ev_switch) (void)hipEventDestroy(t->ev_switch);
     if (t->own_stream) (void)hipStreamDestroy(t->own_stream);
     delete t;
     return PDOG_OK;
@@ -795,7 +842,22 @@ int pdog_set_fill(pdog_tracker *t, int fill)
 int pdog_set_stream(pdog_tracker *t, void *hip_stream)
 {
     if (!t) return fail(PDOG_E_ARG, "pdog_set_stream: null tracker");
-    t->stream = (hipStream_t)hip_stream;
+    hipStream_t ns = (hipStream_t)hip_stream;
+    if (ns == t->stream) return PDOG_OK;
+    // The tracker's scratch (strip partials, two-pass intermediate, DC levels, counters, chain state) is per tracker,
+    // not per stream: whatever is still queued on the previous stream must finish before work on the new one may
+    // touch it.  Stream-ordered, no host wait.
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipEventRecord(t->ev_switch, t->stream));
+    HIP_TRY(hipStreamWaitEvent(ns, t->ev_switch, 0));
+    t->stream = ns;
+    return PDOG_OK;
+}
+
+int pdog_get_stream(const pdog_tracker *t, void **out_hip_stream)
+{
+    if (!t || !out_hip_stream) return fail(PDOG_E_ARG, "pdog_get_stream: null pointer");
+    *out_hip_stream = (void *)t->stream;
     return PDOG_OK;
 }
 
@@ -853,7 +915,7 @@ int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride
         return fail(PDOG_E_RANGE, "pdog_detect_host: guess outside the padded frame (reference: BoundsError)");
     HIP_TRY(hipSetDevice(t->device));
     if (h_resp && !t->d_resp) HIP_TRY(hipMalloc(&t->d_resp, sizeof(float) * (size_t)t->n1 * t->n2));
-    if (!std::getenv("PDOG_HOST_COPY")) {
+    if (!t->sw.host_copy) {
         // Latency path: the tile is packed into pinned, device-mapped memory (fill materialised, as in
         // pdog_detect_batch_host) and the kernels read it in place over PCIe — no copy commands.  On the device the
         // tile is a frame of its own with the guess at its centre; the tile-local answer is mapped back and clamped
@@ -870,7 +932,7 @@ int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride
         }
         uint8_t *d_tile = t->d_tile_map;
         int32_t *d_mail = t->d_mail_map;
-        static const bool trace = std::getenv("PDOG_HOST_TRACE") != nullptr; // diagnostic: where a call's wall time goes
+        const bool trace = t->sw.host_trace; // diagnostic: where a call's wall time goes
         const auto t0 = std::chrono::steady_clock::now();
         pack_tile(t, h_frame, row_stride, guess[0], guess[1], t->h_tile, pitch);
         t->h_pinned[0] = t->r1 + hw + 1;   // the guess is the tile's centre
@@ -887,7 +949,7 @@ int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride
         if (h_resp) HIP_TRY(hipMemcpyAsync(h_resp, t->d_resp, sizeof(float) * (size_t)t->n1 * t->n2, hipMemcpyDeviceToHost, t->stream));
         const auto t2 = std::chrono::steady_clock::now();
         bool done = false;
-        if (armed && !h_resp && !std::getenv("PDOG_HOST_SYNC")) {
+        if (armed && !h_resp && !t->sw.host_sync) {
             const auto deadline = t2 + std::chrono::microseconds(500);
             for (int spin = 0;; ++spin) {
                 if (__atomic_load_n(&t->h_pinned[4], __ATOMIC_ACQUIRE) == ticket) { done = true; break; }
@@ -990,9 +1052,9 @@ extern "C" int pdog_window_tile(const uint8_t *h_frame, int frame_h, int frame_w
 
 namespace {
 
-int ingest_threads()
+int ingest_threads(const pdog_tracker *t)
 {
-    if (const char *e = std::getenv("PDOG_HOST_THREADS")) return std::max(1, std::min(64, std::atoi(e)));
+    if (t->sw.host_threads) return t->sw.host_threads;
     const unsigned hc = std::thread::hardware_concurrency();
     return (int)std::max(1u, std::min(16u, hc ? hc : 1u));
 }
@@ -1028,7 +1090,7 @@ extern "C" int pdog_detect_batch_host(pdog_tracker *t, const uint8_t *h_frames, 
     const size_t tile_bytes = (size_t)th * pitch;
     // chunk: ≈32 MB of tiles, at least 64 windows (the batch kernels want ≥ 1000 strip-waves when they can get them)
     int chunk = (int)std::max<size_t>(64, ((size_t)32 << 20) / tile_bytes);
-    if (const char *e = std::getenv("PDOG_INGEST_CHUNK")) chunk = std::max(1, std::atoi(e));
+    if (t->sw.ingest_chunk) chunk = t->sw.ingest_chunk;
     chunk = std::min(chunk, n);
     constexpr int NS = pdog_tracker::kIngestSlots;
     if (!t->h2d_stream) {
@@ -1098,17 +1160,17 @@ extern "C" int pdog_detect_batch_host(pdog_tracker *t, const uint8_t *h_frames, 
                 waited_for = c;
             }
             const int f = h_frame_index ? h_frame_index[b] : b;
-            static const bool nt_stores = std::getenv("PDOG_INGEST_NO_NT") == nullptr;
+            const bool nt_stores = !t->sw.ingest_no_nt;
             pack_tile_geo(h_frames + (int64_t)f * frame_stride, t->fh, t->fw, row_stride, t->fill, t->L, t->r1, t->r2,
                           h_guesses[2 * b], h_guesses[2 * b + 1], t->h_stage[c % NS] + (size_t)(b - c * chunk) * tile_bytes, pitch, nt_stores);
             packed[c].fetch_add(1, std::memory_order_release);
         }
     };
-    const int nthreads = std::min(ingest_threads(), n);
+    const int nthreads = std::min(ingest_threads(t), n);
     std::vector<std::thread> pool;
     for (int k = 0; k < nthreads; ++k) pool.emplace_back(worker);
     int rc = PDOG_OK;
-    const bool trace = std::getenv("PDOG_INGEST_TRACE") != nullptr; // diagnostic: where the wall time of a call goes
+    const bool trace = t->sw.ingest_trace; // diagnostic: where the wall time of a call goes
     const auto t_begin = std::chrono::steady_clock::now();
     double wait_pack_ms = 0;
     for (int c = 0; c < nchunks && rc == PDOG_OK; ++c) {
@@ -1251,7 +1313,7 @@ extern "C" int pdog_alloc_host(size_t bytes, void **out)
 {
     if (!out || bytes == 0) return fail(PDOG_E_ARG, "pdog_alloc_host: bad argument");
     void *p = nullptr;
-    HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable)); // portable: whichever device is current
     std::memset(p, 0, bytes);
     *out = p;
     return PDOG_OK;

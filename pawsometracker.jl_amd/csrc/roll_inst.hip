@@ -1,0 +1,17 @@
+// roll_inst.hip — explicit instantiations of the rolling-accumulator kernels (dog_roll.hpp) for the kernel
+// lengths of one PDOG_ROLL_SET (roll_lengths.def).  Compiled once per set so that the sets build in parallel;
+// pawsome_dog.hip declares the same instantiations `extern` and only takes their addresses.
+#include "dog_roll.hpp"
+#ifndef PDOG_ROLL_SET
+#error "compile with -DPDOG_ROLL_SET=<n>"
+#endif
+namespace pdog {
+#define PDOG_ROLL_L(LT)                                                                                   \
+    template __global__ void dog_roll_kernel<LT, false, 0>(const LaunchGeo, const f2 *, const f2 *);      \
+    template __global__ void dog_roll_kernel<LT, true, 0>(const LaunchGeo, const f2 *, const f2 *);       \
+    template __global__ void dog_thin_kernel<LT, false>(const LaunchGeo, const f2 *, const f2 *);         \
+    template __global__ void dog_thin_kernel<LT, true>(const LaunchGeo, const f2 *, const f2 *);          \
+    template __global__ void dog_chain_kernel<LT>(const ChainGeo, const f2 *, const f2 *);
+#include "roll_lengths.def"
+#undef PDOG_ROLL_L
+} // namespace pdog

@@ -121,3 +121,40 @@ def test_header_is_plain_c(tmp_path):
                            "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)], text=True).split()
     assert out[0] == "1" and out[1] == "65" and abs(float(out[2]) - 10.616525) < 1e-5
+
+
+def test_c_abi_shard_partition_matches_the_python_one():
+    """pdog_shard_range / pdog_shard_owner (the partition pdog_group_* and its gather compaction use) against
+    shard_range (what the torch.distributed path uses): same contiguous shards, and owner() inverts range()."""
+    L = pt.lib()
+    lo, hi, r, k = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    for n, w in ((4096, 8), (8192, 8), (10, 3), (3, 8), (7, 2), (1, 1), (0, 2), (1000, 7)):
+        for rank in range(w):
+            assert L.pdog_shard_range(n, w, rank, C.byref(lo), C.byref(hi)) == 0
+            assert (lo.value, hi.value) == pt.shard_range(n, rank, w)
+            for win in range(lo.value, hi.value):
+                assert L.pdog_shard_owner(n, w, win, C.byref(r), C.byref(k)) == 0
+                assert (r.value, k.value) == (rank, win - lo.value)
+    assert L.pdog_shard_range(10, 0, 0, C.byref(lo), C.byref(hi)) == _lib.PDOG_E_ARG
+    assert L.pdog_shard_owner(10, 3, 10, C.byref(r), C.byref(k)) == _lib.PDOG_E_ARG
+
+
+def test_group_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pt.PdogError) as e:
+        pt.GroupTracker([0], 64, 64, 25, (45, 45), True, 128)
+    assert e.value.code == _lib.PDOG_E_NODEV and "no CPU path" in str(e.value)
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` starts its own ranks; with fewer than N GPUs visible it must say so and exit
+    non-zero before touching anything (round 1 died on an assert here)."""
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count() + 1
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and f"--gpus {n} requested but only {n - 1} GPU(s) are visible" in p.stderr, (p.returncode, p.stderr[-500:])
+    assert p.stdout.strip() == ""

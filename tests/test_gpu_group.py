@@ -1,0 +1,144 @@
+"""Multi-GPU leg on the one-GPU box: the C ABI's tracker group (pdog_group_*, in-process RCCL ncclGather) with a
+single rank — RCCL accepts a 1-rank communicator, so ncclCommInitAll, the grouped ncclGather on the tracker's stream
+and the result placement all run for real — plus torch.distributed's nccl (= RCCL) backend at world size 1 through
+gather_positions, the bench's --group line, and the stream hand-over of pdog_set_stream.  More ranks need more
+devices: the driver's 8-GPU run is the first time RCCL moves bytes between GPUs."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pt():
+    import pawsometracker_jl_amd as m
+    return m
+
+
+def test_group_of_one_equals_detect_batch(pt, oracle):
+    import torch
+    from oracle import synth
+    for (tw, ws, fh, fw, n) in ((25, (45, 45), 240, 320, 70), (25, (256, 256), 540, 960, 33), (40, (61, 61), 160, 200, 9)):
+        radii = (ws[0] // 2, ws[1] // 2)
+        frames, guesses, _ = synth.make_batch(n, fh, fw, tw, radii, True, seed=11, noise=3)
+        fill = oracle.mode_u8(frames[0])
+        d_f, d_g = torch.from_numpy(frames).cuda(), torch.from_numpy(guesses).cuda()
+        bt = pt.BatchTracker(fh, fw, tw, ws, True, fill)
+        want = bt.detect(d_f, d_g)
+        bt.sync()
+        want = want.cpu().numpy()
+        bt.close()
+        gt = pt.GroupTracker([0], fh, fw, tw, ws, True, fill)
+        assert gt.size() == 1 and gt.shard(n, 0) == (0, n)
+        out = torch.full((n, 2), -1, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        for _ in range(2):                     # second call: buffers and communicator are reused
+            gt.detect([d_f], [d_g], n, out)
+            gt.sync()
+            assert np.array_equal(out.cpu().numpy(), want)
+        # with a frame index: every window looks at frame 0
+        fi = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        gt.detect([d_f], [d_g], n, out, frame_index=[fi])
+        gt.sync()
+        bt = pt.BatchTracker(fh, fw, tw, ws, True, fill)
+        want0 = bt.detect(d_f, d_g, frame_index=fi)
+        bt.sync()
+        assert np.array_equal(out.cpu().numpy(), want0.cpu().numpy())
+        bt.close()
+        gt.close()
+        ref = oracle.detect_batch(frames[:8], fill, oracle.dog_kernel(oracle.sigma(tw), True), radii, guesses[:8])
+        assert np.array_equal(want[:8], ref)
+
+
+def test_group_rejects_bad_devices(pt):
+    import torch
+    nd = torch.cuda.device_count()
+    with pytest.raises(pt.PdogError) as e:
+        pt.GroupTracker([0, nd], 64, 64, 25, (45, 45), True, 128)
+    assert e.value.code == pt._lib.PDOG_E_NODEV
+    with pytest.raises(pt.PdogError) as e:
+        pt.GroupTracker([0, 0], 64, 64, 25, (45, 45), True, 128)
+    assert e.value.code == pt._lib.PDOG_E_ARG and "twice" in str(e.value)
+
+
+_NCCL_WORLD1 = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+import torch, torch.distributed as dist
+import pawsometracker_jl_amd as pt
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+local = torch.stack([torch.arange(7, dtype=torch.int32), torch.arange(7, dtype=torch.int32) * 3], 1).to(dev)
+out = pt.gather_positions(local, 7)
+hs = [pt.gather_positions(local + k, 7, async_op=True) for k in range(3)]
+outs = [h.wait() for h in hs]
+torch.cuda.synchronize()
+assert out.is_cuda and torch.equal(out, local) and all(torch.equal(o, local + k) for k, o in enumerate(outs))
+dist.destroy_process_group()
+print("nccl-world1-ok")
+"""
+
+
+def test_gather_positions_on_the_nccl_backend_world1():
+    """torch.distributed's nccl backend IS RCCL on ROCm: device tensors, device_id= init, blocking and asynchronous
+    gather — the calls bench.py makes with N > 1 — at world size 1, in a child process."""
+    p = subprocess.run([sys.executable, "-c", _NCCL_WORLD1.format(root=ROOT)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "nccl-world1-ok" in p.stdout, (p.returncode, p.stderr[-1500:])
+
+
+def test_bench_group_mode_and_refusal():
+    import torch
+    env = dict(os.environ)
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--group", "--steps", "3", "--warmup", "1", "--batch", "256"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and "pdog_group" in r["config"]["sharding"] and r["value"] > 0 and r["roofline"]["kernel_ms"] > 0
+    if torch.cuda.device_count() == 1:   # more ranks than devices: clear message, non-zero exit, nothing started
+        for extra in ([], ["--group"]):
+            p = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+            assert p.returncode == 2 and "only 1 GPU(s) are visible" in p.stderr, (p.returncode, p.stderr[-500:])
+
+
+def test_alternating_torch_streams_keep_the_scratch_ordered(pt, oracle):
+    """pdog_set_stream hands the tracker's per-tracker scratch (strip partials, two-pass intermediate, counters)
+    from one stream to the next with an event: detect() calls issued alternately under two torch streams must
+    give the answers of serial calls (they raced on the partials before)."""
+    import torch
+    from oracle import synth
+    cases = ((25, (256, 256), 540, 960, 600), (40, (61, 61), 160, 200, 40))   # roll + thin side stream; two-pass scratch
+    for tw, ws, fh, fw, n in cases:
+        radii = (ws[0] // 2, ws[1] // 2)
+        frames, guesses, _ = synth.make_batch(n, fh, fw, tw, radii, True, seed=23, noise=3)
+        fill = oracle.mode_u8(frames[0])
+        ref = oracle.detect_batch(frames[:16], fill, oracle.dog_kernel(oracle.sigma(tw), True), radii, guesses[:16])
+        d_f, d_g = torch.from_numpy(frames).cuda(), torch.from_numpy(guesses).cuda()
+        g2 = torch.roll(d_g, 1, 0).contiguous()      # a second, different batch on the same frames
+        bt = pt.BatchTracker(fh, fw, tw, ws, True, fill)
+        bt.reserve(n)
+        a_ref = bt.detect(d_f, d_g).clone()
+        b_ref = bt.detect(d_f, g2, frame_index=torch.roll(torch.arange(n, dtype=torch.int32, device="cuda"), 1, 0).contiguous()).clone()
+        torch.cuda.synchronize()
+        fi2 = torch.roll(torch.arange(n, dtype=torch.int32, device="cuda"), 1, 0).contiguous()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        outs = []
+        for k in range(6):
+            with torch.cuda.stream(s1 if k % 2 == 0 else s2):
+                outs.append(bt.detect(d_f, d_g) if k % 2 == 0 else bt.detect(d_f, g2, frame_index=fi2))
+        torch.cuda.synchronize()
+        for k, o in enumerate(outs):
+            assert torch.equal(o, a_ref if k % 2 == 0 else b_ref), (tw, k)
+        assert np.array_equal(a_ref[:16].cpu().numpy(), ref)
+        bt.close()
