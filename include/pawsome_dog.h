@@ -108,7 +108,23 @@ int pdog_reserve(pdog_tracker *t, int max_windows);
 int pdog_kernel_for_batch(const pdog_tracker *t, int n, int *out_variant);
 /* Force a kernel specialisation (tuning/tests); -1 = automatic. */
 int pdog_set_variant(pdog_tracker *t, int variant);
+/* Waits for the tracker's stream.  Returns PDOG_E_RANGE when a kernel of the work just finished met a
+ * device-resident guess (pdog_detect_batch, pdog_detect_chains) further outside the frame than the reference's
+ * pad allows — where `trckr(guess)` raises a BoundsError (src/PawsomeTracker.jl:45-46); the flag is cleared by
+ * the call that reports it.  Host-side guesses are checked before anything is launched (pdog_detect_host …). */
 int pdog_sync(pdog_tracker *t);
+
+/* Exact mode (default on).  The reference ranks Float64 dense sums (src/PawsomeTracker.jl:57-59); the kernels rank
+ * FP32 separable sums whose error is bounded by delta = 2^-24 (6 l + 4).  Every kernel also tracks the runner-up
+ * response of its window; when it lies within 2 delta of the maximum, the window's near-maximal pixels are
+ * re-evaluated on the device exactly as the reference evaluates them (dense l x l Float64 correlation, kernel
+ * column-major accumulation order) and the first maximum of those values is returned — so a returned position IS
+ * the reference's, not merely close to it.  pdog_set_exact(t, 0) switches the re-evaluation off (the FP32 argmax
+ * is returned as is); pdog_set_exact(t, 2) re-evaluates EVERY pixel of EVERY window that way (the whole reference
+ * computation on the device: a self-check, orders of magnitude slower).  pdog_get_exact: state, the threshold 2 delta, and how many windows have been re-evaluated
+ * since the tracker was created (any of the out pointers may be NULL; reading the count drains the stream). */
+int pdog_set_exact(pdog_tracker *t, int on);
+int pdog_get_exact(pdog_tracker *t, int *out_on, double *out_threshold, uint64_t *out_refined);
 
 /* ---- the functor, src/PawsomeTracker.jl:55-62, n independent applications ----
  * All pointers are DEVICE pointers.

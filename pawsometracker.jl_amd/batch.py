@@ -29,6 +29,16 @@ class BatchTracker:
     def set_variant(self, variant):
         _lib.check(_lib.lib().pdog_set_variant(self._h, int(variant)))
 
+    def set_exact(self, on):
+        """Exact mode (default on): near-ties of the FP32 ranking are re-decided in the reference's Float64 arithmetic."""
+        _lib.check(_lib.lib().pdog_set_exact(self._h, int(on)))   # 0 off, 1 on, 2 re-evaluate everything (self-check)
+
+    def exact_stats(self):
+        """(on, threshold 2δ, windows re-evaluated so far) — pdog_get_exact."""
+        on, thr, n = C.c_int(), C.c_double(), C.c_uint64()
+        _lib.check(_lib.lib().pdog_get_exact(self._h, C.byref(on), C.byref(thr), C.byref(n)))
+        return bool(on.value), thr.value, int(n.value)
+
     def kernel_for_batch(self, n):
         """Variant id of the kernel family a batch of n windows runs on (300 fused, 200 two-pass, else info().variant)."""
         o = C.c_int()

@@ -1,0 +1,228 @@
+// dog_exact.hpp — positions that are the reference's BY CONSTRUCTION, not by observation.
+//
+// The reference ranks Float64 dense sums: buff[I] = Σ_J Float64(img[I+J])·K[J], accumulated sequentially in kernel
+// column-major order, then findmax (/root/reference/src/PawsomeTracker.jl:57-59).  The kernels of this library
+// rank FP32 separable sums.  Exact ties are settled identically by construction; NEAR ties are not: when the two
+// best responses of a window differ by less than the FP32 evaluation error, FP32 may crown the wrong pixel.
+//
+// Guarantee.  Let F(p) be the reference's Float64 value of pixel p and f(p) the FP32 value of any kernel here.
+// |f(p) − F(p)| ≤ δ for every p, with the a-priori bound (u = 2⁻²⁴, V = max |pixel − dc| ≤ 255, l taps):
+//     row pass     R̂± = Σ_k ĝ±[k]·v, one FMA chain of ≤ l terms, taps rounded once:  |R̂± − R±| ≤ (l + 1)·u·V
+//     column pass  one chain of 2l FMAs over terms bounded by Σ|ĉ±||R̂±| ≤ 2V/255:     ≤ 2l·u·2V/255
+//                  + the row errors times Σ|c±| = 1/255 each + the column taps' rounding 2u·V/255
+//     ⇒ δ = u·(V/255)·(6l + 4)·(1 + ε)  + the reference's own Float64 rounding (≤ l²·2⁻⁵³·2·V/255, negligible)
+// (any summation order, with or without the symmetric pre-add — so it covers every kernel family).  V = 255 is
+// used: δ(l = 65) = 2.35e-5 against a typical peak of 0.09 and a typical peak-to-neighbour gap of 4.7e-4.
+//   1. Every main kernel also tracks the RUNNER-UP value of its window (Peak, dog_kernels.hpp).  If best − runner-up > 2δ
+//      the FP32 argmax is the reference's argmax (the true argmax p* has f(p*) ≥ F(p*) − δ ≥ F(p̂) − δ ≥ f(p̂) − 2δ,
+//      so it is p̂ itself) and nothing else happens: ≈99 % of blob windows.
+//   2. Otherwise the window is REFINED: its FP32 response is recomputed, every pixel with f ≥ max − 2δ (this set
+//      contains p* and every pixel the reference ties with it) is re-evaluated as the reference does it — dense
+//      l×l, Float64, no contraction, kernel column-major order, K = dir·(g₊⊗g₊ − g₋⊗g₋) built in Float64 on the
+//      host, pixel/255.0 by division — and the first maximum in column-major order of THOSE values wins.
+// Flat tiles (every response exactly equal in both arithmetics) would make every pixel a candidate; all their
+// candidates evaluate to the same Float64 value, so the answer is right, only slow.  Cost is otherwise a few
+// dozen dependent 4225-term chains per refined window.
+#pragma once
+#include "dog_kernels.hpp"
+
+namespace pdog {
+
+typedef const double __attribute__((address_space(4))) *k64_ptr; // uniform Float64 kernel reads → scalar loads
+
+// The reference's value of ONE pixel: dense l×l Float64 correlation around window pixel (y, x) (0-based inside the
+// window), accumulated from 0.0 in kernel column-major order, products and sums rounded separately (:57).
+// lut[p] = p / 255.0 (FixedPointNumbers N0f8 → Float64).  Runs in whatever lanes call it.
+__device__ __forceinline__ double exact_pixel(const uint8_t *__restrict__ frame, long long row_stride, int fh, int fw, int fill,
+                                              int i0, int j0, int L, k64_ptr K, const double *lut)
+{
+    // (i0, j0): 0-based frame coordinates of the patch's first row / column (may lie outside the frame)
+    double tmp = 0.0;
+    if (i0 >= 0 && i0 + L <= fh && j0 >= 0 && j0 + L <= fw) {
+        const uint8_t *p0 = frame + (long long)i0 * row_stride + j0;
+        for (int kj = 0; kj < L; ++kj) {
+            const uint8_t *p = p0 + kj;
+            const k64_ptr kc = K + (long long)L * kj;
+            for (int ki = 0; ki < L; ++ki) tmp = __dadd_rn(tmp, __dmul_rn(lut[p[(long long)ki * row_stride]], kc[ki]));
+        }
+    } else {
+        for (int kj = 0; kj < L; ++kj) {
+            const int gj = j0 + kj;
+            const bool colok = gj >= 0 && gj < fw;
+            const k64_ptr kc = K + (long long)L * kj;
+            for (int ki = 0; ki < L; ++ki) {
+                const int gi = i0 + ki;
+                int px = fill; // PaddedView, :48
+                if (colok && gi >= 0 && gi < fh) px = frame[(long long)gi * row_stride + gj];
+                tmp = __dadd_rn(tmp, __dmul_rn(lut[px], kc[ki]));
+            }
+        }
+    }
+    return tmp;
+}
+
+struct Peak64 {
+    double best;
+    int idx;
+};
+__device__ __forceinline__ void peak64_push(Peak64 &p, double v, int lin)
+{
+    if (v > p.best || (v == p.best && lin < p.idx)) { p.best = v; p.idx = lin; }
+}
+__device__ __forceinline__ void peak64_wave_reduce(Peak64 &p)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_down(p.best, off, 64);
+        const int oi = __shfl_down(p.idx, off, 64);
+        peak64_push(p, ov, oi);
+    }
+}
+
+// ---- refinement of window columns [x0, x0 + ncol) by one workgroup of NT threads (a multiple of 64) ----
+// A deliberately plain separable FP32 evaluation (any evaluation within δ serves: see the header), then the
+// reference's arithmetic for the candidates.  Rlds: NA·ncol f2; lut: 256 doubles; ired/dred: NT/64 entries each.
+// Returns the block's Float64 peak in thread 0 (best = −inf if the block holds no candidate).
+__device__ __forceinline__ Peak64 refine_columns(const int NT, const LaunchGeo &g, const uint8_t *__restrict__ frame, int g1, int g2, int x0, int ncol,
+                                                 float thr, tap_ptr trow, tap_ptr tcol, k64_ptr K, f2 *Rlds, double *lut, int *ired, double *dred, bool fill_lut = true)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = NT / 64;
+    const int L = g.L, hw = L >> 1, NA = g.n1 + L - 1;
+    const int ti0 = g1 - g.r1 - 1 - hw, wj0 = g2 - g.r2 - 1 - hw;
+    if (fill_lut)
+        for (int p = tid; p < 256; p += NT) lut[p] = (double)p / 255.0;
+    // DC level: the same fixed sample grid as the main kernels (any level in 0…255 keeps the bound)
+    int sum = dc_sample_sum(g, frame, ti0, wj0, L, tid, NT);
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) ired[wave] = sum;
+    __syncthreads();
+    int tot = 0;
+    for (int w = 0; w < NW; ++w) tot += ired[w];
+    __syncthreads();
+    const int dc = dc_from_sum(tot, g.fill);
+    // row pass: R±[a][x] = Σ_k ĝ±[k]·(pixel[a][x0+x+k] − dc), k ascending
+    for (int e = tid; e < NA * ncol; e += NT) {
+        const int a = e / ncol, x = e - a * ncol;
+        const int gi = ti0 + a, gj0 = wj0 + x0 + x;
+        const bool rowok = gi >= 0 && gi < g.fh;
+        const uint8_t *src = frame + (long long)gi * g.row_stride;
+        f2 acc = f2{0.f, 0.f};
+        for (int k = 0; k < L; ++k) {
+            const int gj = gj0 + k;
+            int px = g.fill;
+            if (rowok && gj >= 0 && gj < g.fw) px = src[gj];
+            acc = fma_bcast((float)(px - dc), trow[k], acc);
+        }
+        Rlds[e] = acc;
+    }
+    __syncthreads();
+    // column pass + candidates
+    Peak64 pk;
+    pk.best = -__builtin_huge_val();
+    pk.idx = 0x7fffffff;
+    for (int e = tid; e < g.n1 * ncol; e += NT) {
+        const int x = e / g.n1, y = e - x * g.n1;
+        float acc = 0.f;
+        for (int t = 0; t < L; ++t) {
+            const f2 r = Rlds[(y + t) * ncol + x];
+            const f2 w = tcol[t];
+            acc = __builtin_fmaf(r.x, w.x, acc);
+            acc = __builtin_fmaf(r.y, w.y, acc);
+        }
+        if (acc >= thr) {
+            const double F = exact_pixel(frame, g.row_stride, g.fh, g.fw, g.fill, ti0 + y, wj0 + x0 + x, L, K, lut);
+            peak64_push(pk, F, (x0 + x) * g.n1 + y);
+        }
+    }
+    peak64_wave_reduce(pk);
+    __syncthreads();
+    if (lane == 0) { dred[wave] = pk.best; ired[wave] = pk.idx; }
+    __syncthreads();
+    if (tid == 0)
+        for (int w = 1; w < NW; ++w) peak64_push(pk, dred[w], ired[w]);
+    __syncthreads();
+    return pk;
+}
+
+// ---- batch refinement: a persistent grid walks the refine list the main kernels left behind ----
+struct RefineGeo {
+    LaunchGeo g;                 // frames, strides, frame_index, guesses, geometry (part_* unused)
+    int *count;                  // length of the refine list; reset by the last workgroup to finish
+    const int *list;
+    const float *list_max;
+    float T;
+    const double *K64;           // l×l, column-major, dir·(g₊⊗g₊ − g₋⊗g₋) (:41-43)
+    int cbw, nblk;               // window columns per work item; work items per window
+    double *part_val;            // [cap][nblk]
+    int *part_idx;               // [cap][nblk]
+    int *part_done;              // [cap] zero between launches
+    int32_t *out_ij;             // [n][2] positions to overwrite
+    int *blocks_done;            // [1] zero between launches: workgroups that have finished (the last one resets the list and publishes)
+    int32_t *done_flag;          // NULL or host-coherent ticket word (see dog_fused.hpp)
+    int32_t done_value;
+};
+
+constexpr int REFINE_NT = 256;
+__host__ __device__ constexpr size_t refine_lds_bytes(int n1, int L, int cbw) { return (size_t)(n1 + L - 1) * cbw * sizeof(f2); }
+
+static __global__ __launch_bounds__(REFINE_NT) void dog_refine_kernel(const RefineGeo rg, const f2 *__restrict__ taps_row,
+                                                                      const f2 *__restrict__ taps_col)
+{
+    constexpr int NT = REFINE_NT, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double lut[256];
+    __shared__ double dred[NW];
+    __shared__ int ired[NW];
+    __shared__ int s_last;
+    const LaunchGeo &g = rg.g;
+    f2 *Rlds = reinterpret_cast<f2 *>(smem);
+    const int tid = threadIdx.x;
+    const int n = __hip_atomic_load(rg.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long items = (long long)n * rg.nblk;
+    for (long long item = blockIdx.x; item < items; item += gridDim.x) {
+        const int e = (int)(item / rg.nblk), cb = (int)(item - (long long)e * rg.nblk);
+        const int b = rg.list[e];
+        const float thr = rg.list_max[e] - rg.T;
+        const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
+        const int fidx = g.frame_index ? g.frame_index[b] : b;
+        const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
+        const int x0 = cb * rg.cbw, ncol = min(rg.cbw, g.n2 - x0);
+        Peak64 pk = refine_columns(NT, g, frame, g1, g2, x0, ncol, thr, as_taps(taps_row), as_taps(taps_col), (k64_ptr)(unsigned long long)rg.K64,
+                                       Rlds, lut, ired, dred);
+        if (tid == 0) {
+            __hip_atomic_store(&rg.part_val[(long long)e * rg.nblk + cb], pk.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&rg.part_idx[(long long)e * rg.nblk + cb], pk.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int old = __hip_atomic_fetch_add(&rg.part_done[e], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old == rg.nblk - 1);
+        }
+        __syncthreads();
+        if (s_last && tid == 0) { // this window's last block: first Float64 maximum over its blocks → position (:59-61)
+            Peak64 w;
+            w.best = -__builtin_huge_val();
+            w.idx = 0x7fffffff;
+            for (int k = 0; k < rg.nblk; ++k)
+                peak64_push(w, __hip_atomic_load(&rg.part_val[(long long)e * rg.nblk + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                            __hip_atomic_load(&rg.part_idx[(long long)e * rg.nblk + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const int x = w.idx / g.n1, y = w.idx - x * g.n1;
+            rg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);
+            rg.out_ij[2 * b + 1] = min(max(g2 - g.r2 + x, 1), g.fw);
+            __hip_atomic_store(&rg.part_done[e], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+    // the last workgroup through leaves the list empty for the next call and, for the single-window host functor,
+    // publishes the ticket (the answer is final only now)
+    if (tid == 0) {
+        __threadfence();
+        const int old = __hip_atomic_fetch_add(rg.blocks_done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (int)gridDim.x - 1) {
+            __hip_atomic_store(rg.blocks_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rg.count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rg.done_flag) {
+                __threadfence_system();
+                __hip_atomic_store(rg.done_flag, rg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
+} // namespace pdog

@@ -18,6 +18,7 @@
 // tap; column pass: k ascending), identical for every output, so flat regions tie exactly.
 #pragma once
 #include "dog_twopass.hpp"
+#include "dog_exact.hpp"
 
 namespace pdog {
 
@@ -32,6 +33,7 @@ struct FusedGeo {
     int32_t *done_flag;  // NULL, or a word in host-coherent memory that receives done_value (system-scope release) once
     int32_t done_value;  // window 0's answer is written: the host functor polls it instead of waiting for the kernel's end
     int progress;        // != 0: done_flag receives k + 1 after every frame k of clip 0 instead (a host consumer follows the chain)
+    const double *K64;   // the reference's dense Float64 kernel, l×l column-major (exact mode, dog_exact.hpp); null = off
 };
 
 constexpr int FUSED_NT = 1024, FUSED_PMAX = 8, FUSED_U = 8;
@@ -138,9 +140,14 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
     __shared__ float s_val[NW];
     __shared__ int s_idx[NW];
     __shared__ int s_guess[2];
+    __shared__ float s_sec[NW];
+    __shared__ double s_lut[256], s_dred[NW]; // exact mode: p / 255.0 and the wave peaks of the Float64 re-evaluation
+    __shared__ int s_refine;
+    __shared__ float s_max;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const tap_ptr trow = as_taps(taps_row), tcol = as_taps(taps_col);
+    if (fg.K64 && tid < 256) s_lut[tid] = (double)tid / 255.0;
 
     // tile columns c ≥ TWin and RT columns a ≥ NA are only ever read by the sliding windows of masked outputs: zero once
     for (int r = wave; r < NA; r += NW)
@@ -240,8 +247,8 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
         __syncthreads();
         stamp(2);
         // ---- column pass + peak ----
-        float best = -__builtin_huge_valf();
-        int best_idx = 0x7fffffff;
+        Peak pk;
+        peak_init(pk);
         {
             const int ngy = (g.n1 + fg.pc - 1) / fg.pc, ntask = g.n2 * ngy;
             auto run = [&](auto Pc) {
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
                             const float v = acc[o].x + acc[o].y;
                             const int lin = x * g.n1 + y;
                             if (RESP && !DIAG) g.resp[(long long)b * g.n1 * g.n2 + lin] = v;
-                            if (v > best || (v == best && lin < best_idx)) { best = v; best_idx = lin; }
+                            peak_push(pk, v, lin);
                         }
                     }
                 }
@@ -270,39 +277,78 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
             default: run(std::integral_constant<int, 8>{}); break;
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_down(best, off, 64);
-            const int oi = __shfl_down(best_idx, off, 64);
-            if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
-        }
-        if (lane == 0) { s_val[wave] = best; s_idx[wave] = best_idx; }
+        peak_wave_reduce(pk);
+        if (lane == 0) { s_val[wave] = pk.best; s_idx[wave] = pk.idx; s_sec[wave] = pk.second; }
         stamp(5);
         __syncthreads();
         stamp(6);
+        const bool publish = fg.done_flag && b == 0 && (fg.progress || k == fg.chain_len - 1);
+        int32_t *const o_ij = fg.out_ij + 2 * ((long long)b * fg.chain_len + k);
         if (wave == 0) { // the 16 wave peaks: lanes 0..15 of wave 0, same tie rule
-            best = lane < NW ? s_val[lane] : -__builtin_huge_valf();
-            best_idx = lane < NW ? s_idx[lane] : 0x7fffffff;
-#pragma unroll
-            for (int off = NW / 2; off > 0; off >>= 1) {
-                const float ov = __shfl_down(best, off, 64);
-                const int oi = __shfl_down(best_idx, off, 64);
-                if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
-            }
+            peak_init(pk);
+            if (lane < NW) { pk.best = s_val[lane]; pk.idx = s_idx[lane]; pk.second = s_sec[lane]; }
+            peak_wave_reduce(pk, NW);
             if (lane == 0) {
-                const int x = best_idx / g.n1, y = best_idx - x * g.n1;
+                const int x = pk.idx / g.n1, y = pk.idx - x * g.n1;
                 const int i = min(max(g1 - g.r1 + y, 1), g.fh);   // :60-61
                 const int j = min(max(g2 - g.r2 + x, 1), g.fw);
-                int32_t *o = fg.out_ij + 2 * ((long long)b * fg.chain_len + k);
-                o[0] = i;
-                o[1] = j;
+                o_ij[0] = i;
+                o_ij[1] = j;
                 s_guess[0] = i;
                 s_guess[1] = j;
-                if (fg.done_flag && b == 0 && (fg.progress || k == fg.chain_len - 1))
+                if (k == 0) range_check(g.ex, g1, g2, hw, g.fh, g.fw);
+                // exact mode (dog_exact.hpp): a runner-up within 2δ of the maximum → the reference's own arithmetic decides
+                const bool rf = fg.K64 && (pk.best - pk.second <= g.ex.T);
+                s_refine = rf;
+                s_max = pk.best;
+                if (rf) atomicAdd(g.ex.stat, 1ull);
+                if (!rf && publish)
                     __hip_atomic_store(fg.done_flag, fg.progress ? k + 1 : fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         __syncthreads();
+        if (s_refine) {
+            // RT is still in LDS: one more sweep of the column pass finds the pixels within 2δ of the maximum; each is
+            // re-evaluated as the reference does it (dense l×l Float64 in kernel column-major order, :57) from the LDS
+            // tile — A holds (float)(pixel − dc), exact integers — and the first maximum of THOSE values wins (:59).
+            const float thr = s_max - g.ex.T;
+            const k64_ptr K = (k64_ptr)(unsigned long long)fg.K64;
+            const int dc = dc_from_sum([&] { int t = 0; for (int w = 0; w < NW; ++w) t += s_sum[w]; return t; }(), g.fill);
+            Peak64 p64;
+            p64.best = -__builtin_huge_val();
+            p64.idx = 0x7fffffff;
+            for (int e = tid; e < g.n1 * g.n2; e += NT) {
+                const int x = e / g.n1, y = e - x * g.n1;
+                const f2 *a = Vs + x * fg.pitchV + y;
+                f2 acc = f2{0.f, 0.f};
+                for (int t = 0; t < L; ++t) acc = fma_pair(a[t], tcol[t], acc);
+                if (acc.x + acc.y >= thr) {
+                    double tmp = 0.0;
+                    for (int kj = 0; kj < L; ++kj) {
+                        const float *col = A + y * fg.pitchA + x + kj;
+                        const k64_ptr kc = K + (long long)L * kj;
+                        for (int ki = 0; ki < L; ++ki) tmp = __dadd_rn(tmp, __dmul_rn(s_lut[(int)col[ki * fg.pitchA] + dc], kc[ki]));
+                    }
+                    peak64_push(p64, tmp, e);
+                }
+            }
+            peak64_wave_reduce(p64);
+            if (lane == 0) { s_dred[wave] = p64.best; s_idx[wave] = p64.idx; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < NW; ++w) peak64_push(p64, s_dred[w], s_idx[w]);
+                const int x = p64.idx / g.n1, y = p64.idx - x * g.n1;
+                const int i = min(max(g1 - g.r1 + y, 1), g.fh);
+                const int j = min(max(g2 - g.r2 + x, 1), g.fw);
+                o_ij[0] = i;
+                o_ij[1] = j;
+                s_guess[0] = i;
+                s_guess[1] = j;
+                if (publish)
+                    __hip_atomic_store(fg.done_flag, fg.progress ? k + 1 : fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __syncthreads();
+        }
         stamp(3);
         g1 = s_guess[0];   // :167 — the next frame's guess
         g2 = s_guess[1];

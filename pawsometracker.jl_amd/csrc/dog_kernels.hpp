@@ -33,14 +33,83 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef const f2 __attribute__((address_space(4))) *tap_ptr;
 __device__ __forceinline__ tap_ptr as_taps(const f2 *p) { return (tap_ptr)(unsigned long long)p; }
 
+// ---- running peak with runner-up (exact mode, dog_exact.hpp) ----
+// The first maximum in column-major order (findmax, :59) and the largest response of any OTHER pixel: when the two
+// are further apart than twice the FP32 error bound the FP32 argmax is provably the reference's.
+struct Peak {
+    float best;
+    int idx;      // column-major index of the first maximum
+    float second; // runner-up value (−inf if there is none)
+};
+__device__ __forceinline__ void peak_init(Peak &p)
+{
+    p.best = -__builtin_huge_valf();
+    p.idx = 0x7fffffff;
+    p.second = -__builtin_huge_valf();
+}
+__device__ __forceinline__ void peak_push(Peak &p, float v, int lin)
+{
+    p.second = __builtin_amdgcn_fmed3f(v, p.best, p.second); // second ≤ best always: the median is the new runner-up
+    if (v > p.best || (v == p.best && lin < p.idx)) { p.best = v; p.idx = lin; }
+}
+// merge the peak of a disjoint set of pixels
+__device__ __forceinline__ void peak_merge(Peak &p, float ov, int oi, float os)
+{
+    p.second = fmaxf(fmaxf(p.second, os), fminf(p.best, ov));
+    if (ov > p.best || (ov == p.best && oi < p.idx)) { p.best = ov; p.idx = oi; }
+}
+__device__ __forceinline__ void peak_wave_reduce(Peak &p, int width = 64)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        if (off < width) {
+            const float ov = __shfl_down(p.best, off, 64);
+            const int oi = __shfl_down(p.idx, off, 64);
+            const float os = __shfl_down(p.second, off, 64);
+            peak_merge(p, ov, oi, os);
+        }
+    }
+}
+
+// What the main kernels hand to the refinement (dog_exact.hpp): windows whose two best FP32 responses lie within
+// T = 2δ of each other are listed for a Float64 re-evaluation of their near-maximal pixels.
+struct ExactCtl {
+    int *count;               // [1] length of the refine list (the refinement kernel leaves it at zero); null = exact mode off
+    int *list;                // [cap] windows to refine
+    float *list_max;          // [cap] their FP32 maxima
+    unsigned long long *stat; // [1] windows listed since the tracker was created (diagnostics)
+    int *range_err;           // host-coherent word: set when a guess lies where the reference raises BoundsError (:45-46)
+    float T;                  // 2δ
+};
+// one thread, after a window's partials have been combined
+__device__ __forceinline__ void exact_flag(const ExactCtl &x, int b, float best, float second)
+{
+    if (x.count && best - second <= x.T) {
+        const int k = atomicAdd(x.count, 1);
+        x.list[k] = b;
+        x.list_max[k] = best;
+        atomicAdd(x.stat, 1ull);
+    }
+}
+// The reference's PaddedView extends radii + l past the frame (:45-46) and the filter reads radii + l÷2 around the
+// guess: a guess outside [−l÷2, sz + l÷2 + 1] raises BoundsError there.  Device-resident guesses cannot be checked
+// before the launch, so the kernels raise a flag that pdog_sync reports.
+__device__ __forceinline__ void range_check(const ExactCtl &x, int g1, int g2, int hw, int fh, int fw)
+{
+    if (x.range_err && (g1 < -hw || g1 > fh + hw + 1 || g2 < -hw || g2 > fw + hw + 1))
+        __hip_atomic_store(x.range_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct LaunchGeo {
     const uint8_t *__restrict__ frames;
     long long frame_stride, row_stride;
     const int *__restrict__ frame_index; // may be null
     const int *__restrict__ guesses;     // n x 2, 1-based (row, col)
     float *__restrict__ resp;            // only written by RESP instantiations
-    float *__restrict__ part_val;        // n x nstrips
-    int *__restrict__ part_idx;          // n x nstrips
+    float *__restrict__ part_val;        // n x nslots
+    int *__restrict__ part_idx;          // n x nslots
+    float *__restrict__ part_sec;        // n x nslots: runner-up value of each partial
+    ExactCtl ex;
     int fh, fw, r1, r2, n1, n2, L, fill, nstrips, n;
     int RR, pitchA;                      // only read by runtime-L variants
     int nblocks;                         // n * nstrips
@@ -61,6 +130,29 @@ __host__ __device__ constexpr int ring_rows(int CH, int L, int Q)
     // rows a col-pass span can touch: CH new + L-1 halo + (Q-1) slack when the
     // chunk cadence leaves a partial Q-group behind; multiple of 4 for the wrap logic
     return round_up(CH + L - 1 + (((CH % Q) == 0 && ((L - 1) % Q) == 0) ? 0 : Q - 1), 4);
+}
+
+// The fixed 32×32 sample grid over the window's padded tile that decides the DC level (see dog_window_kernel):
+// thread `tid` of `nthreads` adds up its share; callers reduce and finish with dc_from_sum.
+__device__ __forceinline__ int dc_sample_sum(const LaunchGeo &g, const uint8_t *__restrict__ frame, int ti0, int wj0,
+                                             int L, int tid, int nthreads)
+{
+    const int tH = g.n1 + L - 1, tW = g.n2 + L - 1;
+    int sum = 0;
+    for (int k = tid; k < 1024; k += nthreads) {
+        const int gi = ti0 + (int)(((long long)(k >> 5) * tH) >> 5);
+        const int gj = wj0 + (int)(((long long)(k & 31) * tW) >> 5);
+        int v = g.fill;
+        if (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) v = frame[(long long)gi * g.row_stride + gj];
+        sum += v;
+    }
+    return sum;
+}
+__device__ __forceinline__ int dc_from_sum(int total, int fill)
+{
+    int dc = (total + 512) >> 10;
+    if (abs(dc - fill) <= 8) dc = fill;
+    return dc;
 }
 
 __device__ __forceinline__ f2 fma_bcast(float a, f2 t, f2 c)
@@ -248,8 +340,8 @@ __global__ __launch_bounds__(NT, 2) void dog_window_kernel(const LaunchGeo g, co
         if (abs(dc - g.fill) <= 8) dc = g.fill;
     }
 
-    float best = -__builtin_huge_valf();
-    int best_idx = 0x7fffffff;
+    Peak pk;
+    peak_init(pk);
     int y_done = 0;
 
     for (int c0 = 0; c0 < NA; c0 += CH) {
@@ -330,10 +422,12 @@ __global__ __launch_bounds__(NT, 2) void dog_window_kernel(const LaunchGeo g, co
                     }
                     // first maximum in column-major order (findmax, :59); the index search only
                     // runs for a lane whose group reaches its running maximum (rare after warm-up)
-                    if (m >= best && nvalid > 0) {
+                    if (m >= pk.best && nvalid > 0) {
 #pragma unroll
                         for (int o = 0; o < Q; ++o)
-                            if (v[o] > best || (v[o] == best && lin0 + o < best_idx)) { best = v[o]; best_idx = lin0 + o; }
+                            if (o < nvalid) peak_push(pk, v[o], lin0 + o);
+                    } else {
+                        pk.second = fmaxf(pk.second, m); // every value of the group is below the lane's best
                     }
                 }
             }
@@ -343,42 +437,35 @@ __global__ __launch_bounds__(NT, 2) void dog_window_kernel(const LaunchGeo g, co
     }
 
     // ---- peak: wave shuffle reduction, then across waves through LDS ----
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_down(best, off, 64);
-        const int oi = __shfl_down(best_idx, off, 64);
-        if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
-    }
+    peak_wave_reduce(pk);
     float *sval = reinterpret_cast<float *>(smem);
     int *sidx = reinterpret_cast<int *>(smem + 64);
-    if (lane == 0) { sval[wave] = best; sidx[wave] = best_idx; }
+    float *ssec = reinterpret_cast<float *>(smem + 128);
+    if (lane == 0) { sval[wave] = pk.best; sidx[wave] = pk.idx; ssec[wave] = pk.second; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < NW; ++w) {
-            const float ov = sval[w];
-            const int oi = sidx[w];
-            if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
-        }
-        g.part_val[b * g.nslots + s] = best;
-        g.part_idx[b * g.nslots + s] = best_idx;
+        for (int w = 1; w < NW; ++w) peak_merge(pk, sval[w], sidx[w], ssec[w]);
+        g.part_val[b * g.nslots + s] = pk.best;
+        g.part_idx[b * g.nslots + s] = pk.idx;
+        g.part_sec[b * g.nslots + s] = pk.second;
     }
 }
 
 // Combine the strips of each window, map window-local → absolute, clamp
 // (src/PawsomeTracker.jl:60-61).  One thread per window.
 static __global__ void dog_finalize_kernel(const float *__restrict__ part_val, const int *__restrict__ part_idx,
-                                    const int *__restrict__ guesses, int *__restrict__ out_ij,
-                                    int n, int nstrips, int r1, int r2, int n1, int fh, int fw)
+                                           const float *__restrict__ part_sec, const ExactCtl ex,
+                                           const int *__restrict__ guesses, int *__restrict__ out_ij,
+                                           int n, int nstrips, int r1, int r2, int n1, int fh, int fw, int hw)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n) return;
-    float best = part_val[b * nstrips];
-    int idx = part_idx[b * nstrips];
-    for (int s = 1; s < nstrips; ++s) {
-        const float v = part_val[b * nstrips + s];
-        const int i = part_idx[b * nstrips + s];
-        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
-    }
+    Peak pk;
+    peak_init(pk);
+    for (int s = 0; s < nstrips; ++s) peak_merge(pk, part_val[b * nstrips + s], part_idx[b * nstrips + s], part_sec[b * nstrips + s]);
+    exact_flag(ex, b, pk.best, pk.second);
+    range_check(ex, guesses[2 * b], guesses[2 * b + 1], hw, fh, fw);
+    const int idx = pk.idx;
     const int x = idx / n1, y = idx - x * n1;
     int i = guesses[2 * b] - r1 + y;
     int j = guesses[2 * b + 1] - r2 + x;

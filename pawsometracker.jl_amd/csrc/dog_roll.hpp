@@ -28,6 +28,7 @@
 // (≤ 256 VGPRs) is enough once there are no barriers.
 #pragma once
 #include "dog_kernels.hpp"
+#include "dog_exact.hpp"
 #include <type_traits>
 
 namespace pdog {
@@ -49,29 +50,6 @@ __host__ __device__ constexpr int roll_slots(int L) { return (L - 1 + ROLL_CH + 
 __host__ __device__ constexpr int roll_sb(int L) { return ((ROLL_TW + L - 1 + 7) / 8 + 3) / 4 * 4; }
 __host__ __device__ constexpr int roll_pa(int L) { return (8 * roll_sb(L)) | 1; }
 __host__ __device__ constexpr size_t roll_lds_bytes(int L) { return (size_t)ROLL_CH * roll_pa(L) * 4 + (size_t)ROLL_CH * ROLL_PR * 8; }
-
-// The fixed 32×32 sample grid over the window's padded tile that decides the DC level (see
-// dog_kernels.hpp): thread `tid` of `nthreads` adds up its share; callers reduce and finish.
-__device__ __forceinline__ int dc_sample_sum(const LaunchGeo &g, const uint8_t *__restrict__ frame, int ti0, int wj0,
-                                             int L, int tid, int nthreads)
-{
-    const int tH = g.n1 + L - 1, tW = g.n2 + L - 1;
-    int sum = 0;
-    for (int k = tid; k < 1024; k += nthreads) {
-        const int gi = ti0 + (int)(((long long)(k >> 5) * tH) >> 5);
-        const int gj = wj0 + (int)(((long long)(k & 31) * tW) >> 5);
-        int v = g.fill;
-        if (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) v = frame[(long long)gi * g.row_stride + gj];
-        sum += v;
-    }
-    return sum;
-}
-__device__ __forceinline__ int dc_from_sum(int total, int fill)
-{
-    int dc = (total + 512) >> 10;
-    if (abs(dc - fill) <= 8) dc = fill;
-    return dc;
-}
 
 // Re-derive a tap pointer through an empty asm: the scalar loads that use it cannot be hoisted above
 // this point (hoisted, every block's taps are live at once and the SGPRs spill through v_writelane).
@@ -232,7 +210,7 @@ __device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], con
 template <int LT, bool RESP, int ABL>
 __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restrict__ taps_row, const f2 *__restrict__ taps_col,
                                            unsigned char *smem, const uint8_t *__restrict__ frame, int g1, int g2, int s,
-                                           int b, int logical, float &best_out, int &best_idx_out)
+                                           int b, int logical, Peak &peak_out)
 {
     constexpr int L = LT, hw = L / 2, S = roll_slots(L), CH = ROLL_CH, P = ROLL_P, TW = ROLL_TW;
     constexpr int NBODY = S / CH;
@@ -296,7 +274,7 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
     f2 acc2[S / 2];
 #pragma unroll
     for (int j = 0; j < S / 2; ++j) acc2[j] = f2{0.f, 0.f};
-    float best = -__builtin_huge_valf();
+    float best = -__builtin_huge_valf(), second = -__builtin_huge_valf();
     int best_y = 0;
 
     const tap_ptr trow = as_taps(taps_row);
@@ -363,7 +341,10 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
                     const float v = (slot & 1) ? acc2[slot / 2].y : acc2[slot / 2].x;
                     const bool rowok = full || ((ybase + i >= 0) && (ybase + i < g.n1));
                     if (RESP && rowok && lane < ws) g.resp[resp_base + (long long)(x0 + lane) * g.n1 + ybase + i] = v;
-                    if (rowok && v > best) { best = v; best_y = ybase + i; }
+                    if (rowok) {
+                        second = __builtin_amdgcn_fmed3f(v, best, second); // runner-up of the lane's column (exact mode)
+                        if (v > best) { best = v; best_y = ybase + i; }
+                    }
                 }
             }
             // the emitted slots start their next output from zero (they are reused S rows later)
@@ -399,16 +380,13 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
         const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0 && g.resp) { g.resp[2 * logical] = (float)(c1 - stamp_c0); g.resp[2 * logical + 1] = (float)(r1 - stamp_r0); }
     }
-    int best_idx = (x0 + lane) * g.n1 + best_y;
-    if (lane >= ws) { best = -__builtin_huge_valf(); best_idx = 0x7fffffff; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_down(best, off, 64);
-        const int oi = __shfl_down(best_idx, off, 64);
-        if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
-    }
-    best_out = best;       // valid in lane 0
-    best_idx_out = best_idx;
+    Peak pk;
+    pk.best = best;
+    pk.second = second;
+    pk.idx = (x0 + lane) * g.n1 + best_y;
+    if (lane >= ws) peak_init(pk);
+    peak_wave_reduce(pk);
+    peak_out = pk;         // valid in lane 0
 }
 
 
@@ -426,12 +404,12 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
     const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
     const int fidx = g.frame_index ? g.frame_index[b] : b;
     const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
-    float best;
-    int best_idx;
-    roll_strip<LT, RESP, ABL>(g, taps_row, taps_col, smem, frame, g1, g2, s, b, logical, best, best_idx);
+    Peak pk;
+    roll_strip<LT, RESP, ABL>(g, taps_row, taps_col, smem, frame, g1, g2, s, b, logical, pk);
     if (threadIdx.x == 0) {
-        g.part_val[b * g.nslots + s] = best;
-        g.part_idx[b * g.nslots + s] = best_idx;
+        g.part_val[b * g.nslots + s] = pk.best;
+        g.part_idx[b * g.nslots + s] = pk.idx;
+        g.part_sec[b * g.nslots + s] = pk.second;
     }
 }
 
@@ -442,6 +420,9 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
 // columns are not used here: the last strip overlaps instead (bit-identical values either way).
 struct ChainGeo {
     LaunchGeo g;                         // frames = first frame of clip 0; guesses/frame_index unused
+    const double *K64;                   // the reference's dense Float64 kernel (exact mode; null = off), dog_exact.hpp
+    int lds_bytes;                       // dynamic LDS of the workgroup (the refinement's scratch)
+    const f2 *taps_col_plain;            // (s·g₊[k], −s·g₋[k]) per tap: the refinement's column taps (taps_col is the roll kernel's paired table)
     const int *__restrict__ start;       // n_clips x 2, 1-based (row, col)
     int *__restrict__ out_ij;            // n_clips x n_frames x 2
     int n_frames;                        // per clip; clip c's frame k is frame c*n_frames + k
@@ -452,34 +433,69 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int cur[2];
-    __shared__ float pv[8];
+    __shared__ float pv[8], ps[8];
     __shared__ int pi[8];
+    __shared__ double lut[256], dred[8];
+    __shared__ int ired[8];
+    __shared__ int s_refine;
+    __shared__ float s_max;
     const LaunchGeo &g = cg.g;
     const int tid = threadIdx.x, wave = tid >> 6, nst = blockDim.x >> 6;
     const int c = blockIdx.x;
-    if (tid == 0) { cur[0] = cg.start[2 * c]; cur[1] = cg.start[2 * c + 1]; }
+    if (tid == 0) {
+        cur[0] = cg.start[2 * c];
+        cur[1] = cg.start[2 * c + 1];
+        range_check(g.ex, cur[0], cur[1], LT / 2, g.fh, g.fw);
+    }
+    if (cg.K64)
+        for (int p = tid; p < 256; p += blockDim.x) lut[p] = (double)p / 255.0;
     __syncthreads();
     for (int k = 0; k < cg.n_frames; ++k) {
         const int g1 = cur[0], g2 = cur[1];
         const uint8_t *__restrict__ frame = g.frames + ((long long)c * cg.n_frames + k) * g.frame_stride;
-        float best;
-        int best_idx;
-        roll_strip<LT, false, 0>(g, taps_row, taps_col, smem + wave * roll_lds_bytes(LT), frame, g1, g2, wave, 0, 0, best, best_idx);
-        if ((tid & 63) == 0) { pv[wave] = best; pi[wave] = best_idx; }
+        Peak pk;
+        roll_strip<LT, false, 0>(g, taps_row, taps_col, smem + wave * roll_lds_bytes(LT), frame, g1, g2, wave, 0, 0, pk);
+        if ((tid & 63) == 0) { pv[wave] = pk.best; pi[wave] = pk.idx; ps[wave] = pk.second; }
         __syncthreads();
         if (tid == 0) {
-            float bv = pv[0];
-            int bi = pi[0];
-            for (int w = 1; w < nst; ++w)
-                if (pv[w] > bv || (pv[w] == bv && pi[w] < bi)) { bv = pv[w]; bi = pi[w]; }
-            const int x = bi / g.n1, y = bi - x * g.n1;
+            Peak w;
+            peak_init(w);
+            for (int q = 0; q < nst; ++q) peak_merge(w, pv[q], pi[q], ps[q]);
+            const int x = w.idx / g.n1, y = w.idx - x * g.n1;
             const int i = min(max(g1 - g.r1 + y, 1), g.fh);   // :60-61
             const int j = min(max(g2 - g.r2 + x, 1), g.fw);
             int *o = cg.out_ij + 2 * ((long long)c * cg.n_frames + k);
             o[0] = i; o[1] = j;
             cur[0] = i; cur[1] = j;
+            s_refine = cg.K64 && (w.best - w.second <= g.ex.T);
+            s_max = w.best;
+            if (s_refine) atomicAdd(g.ex.stat, 1ull);
         }
         __syncthreads();
+        if (s_refine) {
+            // near-tie: the chain cannot go on before the reference's own arithmetic has decided (dog_exact.hpp);
+            // the strips' LDS is free between frames and holds the row-pass block
+            const int NA = g.n1 + LT - 1;
+            const int cbw = max(1, min(g.n2, cg.lds_bytes / (NA * (int)sizeof(f2))));
+            Peak64 wk;
+            wk.best = -__builtin_huge_val();
+            wk.idx = 0x7fffffff;
+            for (int x0 = 0; x0 < g.n2; x0 += cbw) {
+                const Peak64 bk = refine_columns(blockDim.x, g, frame, g1, g2, x0, min(cbw, g.n2 - x0), s_max - g.ex.T, as_taps(taps_row),
+                                                 as_taps(cg.taps_col_plain), (k64_ptr)(unsigned long long)cg.K64,
+                                                 reinterpret_cast<f2 *>(smem), lut, ired, dred, false);
+                if (tid == 0) peak64_push(wk, bk.best, bk.idx);
+            }
+            if (tid == 0) {
+                const int x = wk.idx / g.n1, y = wk.idx - x * g.n1;
+                const int i = min(max(g1 - g.r1 + y, 1), g.fh);
+                const int j = min(max(g2 - g.r2 + x, 1), g.fw);
+                int *o = cg.out_ij + 2 * ((long long)c * cg.n_frames + k);
+                o[0] = i; o[1] = j;
+                cur[0] = i; cur[1] = j;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -526,7 +542,7 @@ __global__ __launch_bounds__(256) void dog_thin_kernel(const LaunchGeo g, const 
     const tap_ptr tcol = as_taps(taps_col);
 
     __shared__ int ssum[NW];
-    __shared__ float sval[NW];
+    __shared__ float sval[NW], ssec[NW];
     __shared__ int sidx[NW];
     int dc;
     {
@@ -574,8 +590,8 @@ __global__ __launch_bounds__(256) void dog_thin_kernel(const LaunchGeo g, const 
     }
     __syncthreads();
     // ---- column pass + argmax: outputs y = tid, tid + 256, … ----
-    float best = -__builtin_huge_valf();
-    int best_idx = 0x7fffffff;
+    Peak pk;
+    peak_init(pk);
     for (int y = tid; y < g.n1; y += NT) {
         float acc = 0.f;
 #pragma unroll 13
@@ -587,21 +603,16 @@ __global__ __launch_bounds__(256) void dog_thin_kernel(const LaunchGeo g, const 
         }
         const int lin = x * g.n1 + y;
         if (RESP) g.resp[(long long)b * g.n1 * g.n2 + lin] = acc;
-        if (acc > best || (acc == best && lin < best_idx)) { best = acc; best_idx = lin; }
+        peak_push(pk, acc, lin);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_down(best, off, 64);
-        const int oi = __shfl_down(best_idx, off, 64);
-        if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
-    }
-    if (lane == 0) { sval[wave] = best; sidx[wave] = best_idx; }
+    peak_wave_reduce(pk);
+    if (lane == 0) { sval[wave] = pk.best; sidx[wave] = pk.idx; ssec[wave] = pk.second; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < NW; ++w)
-            if (sval[w] > best || (sval[w] == best && sidx[w] < best_idx)) { best = sval[w]; best_idx = sidx[w]; }
-        g.part_val[b * g.nslots + g.nstrips + rc] = best;
-        g.part_idx[b * g.nslots + g.nstrips + rc] = best_idx;
+        for (int w = 1; w < NW; ++w) peak_merge(pk, sval[w], sidx[w], ssec[w]);
+        g.part_val[b * g.nslots + g.nstrips + rc] = pk.best;
+        g.part_idx[b * g.nslots + g.nstrips + rc] = pk.idx;
+        g.part_sec[b * g.nslots + g.nstrips + rc] = pk.second;
     }
 }
 

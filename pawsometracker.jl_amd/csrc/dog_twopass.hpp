@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, con
     const int L = g.L;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f2 *Vs = reinterpret_cast<f2 *>(smem);
-    __shared__ float sval[NW];
+    __shared__ float sval[NW], ssec[NW];
     __shared__ int sidx[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b_local = blockIdx.x / tg.hblocks_per_win;
@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, con
     __syncthreads();
     const tap_ptr taps = as_taps(taps_col);
     const int r = tid % HR, gx = tid / HR;
-    float best = -__builtin_huge_valf();
-    int best_idx = 0x7fffffff;
+    Peak pk;
+    peak_init(pk);
     // a workgroup covers XG·P columns per round; wide windows take several rounds
     for (int xb = gx * P; xb < g.n1; xb += XG * P) { // xb: first output row y of this lane's group
         const f2 *a = Vs + r * tg.pitchV + xb;
@@ -267,54 +267,48 @@ __global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, con
                     const float v = acc[o].x + acc[o].y;
                     const int lin = x * g.n1 + y;
                     if (RESP) g.resp[(long long)b * g.n1 * g.n2 + lin] = v;
-                    if (v > best) { best = v; best_idx = lin; } // y ascending ⇒ lin ascending: strict > keeps the first
+                    peak_push(pk, v, lin);
                 }
             }
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_down(best, off, 64);
-        const int oi = __shfl_down(best_idx, off, 64);
-        if (ov > best || (ov == best && oi < best_idx)) { best = ov; best_idx = oi; }
-    }
-    if (lane == 0) { sval[wave] = best; sidx[wave] = best_idx; }
+    peak_wave_reduce(pk);
+    if (lane == 0) { sval[wave] = pk.best; sidx[wave] = pk.idx; ssec[wave] = pk.second; }
     __syncthreads();
     __shared__ int s_last;
     if (tid == 0) {
-        for (int w = 1; w < NW; ++w)
-            if (sval[w] > best || (sval[w] == best && sidx[w] < best_idx)) { best = sval[w]; best_idx = sidx[w]; }
+        for (int w = 1; w < NW; ++w) peak_merge(pk, sval[w], sidx[w], ssec[w]);
         if (FIN) {
-            __hip_atomic_store(&g.part_val[b * g.nslots + rb], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&g.part_idx[b * g.nslots + rb], best_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&g.part_val[b * g.nslots + rb], pk.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&g.part_idx[b * g.nslots + rb], pk.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&g.part_sec[b * g.nslots + rb], pk.second, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int old = __hip_atomic_fetch_add(&tg.counter[b], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             s_last = (old == tg.hblocks_per_win - 1);
         } else {
-            g.part_val[b * g.nslots + rb] = best;
-            g.part_idx[b * g.nslots + rb] = best_idx;
+            g.part_val[b * g.nslots + rb] = pk.best;
+            g.part_idx[b * g.nslots + rb] = pk.idx;
+            g.part_sec[b * g.nslots + rb] = pk.second;
         }
     }
     if (FIN) {
         __syncthreads();
         if (s_last && wave == 0) {
-            float bv = -__builtin_huge_valf();
-            int bi = 0x7fffffff;
-            for (int sl = lane; sl < g.nslots; sl += 64) {
-                const float v = __hip_atomic_load(&g.part_val[b * g.nslots + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int i = __hip_atomic_load(&g.part_idx[b * g.nslots + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const float ov = __shfl_down(bv, off, 64);
-                const int oi = __shfl_down(bi, off, 64);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
+            Peak w;
+            peak_init(w);
+            for (int sl = lane; sl < g.nslots; sl += 64)
+                peak_merge(w, __hip_atomic_load(&g.part_val[b * g.nslots + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                           __hip_atomic_load(&g.part_idx[b * g.nslots + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                           __hip_atomic_load(&g.part_sec[b * g.nslots + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            peak_wave_reduce(w);
             if (lane == 0) {
+                const int bi = w.idx;
                 const int x = bi / g.n1, y = bi - x * g.n1;
                 tg.out_ij[2 * b] = min(max(g.guesses[2 * b] - g.r1 + y, 1), g.fh);       // :60-61
                 tg.out_ij[2 * b + 1] = min(max(g.guesses[2 * b + 1] - g.r2 + x, 1), g.fw);
+                exact_flag(g.ex, b, w.best, w.second);
+                range_check(g.ex, g.guesses[2 * b], g.guesses[2 * b + 1], L >> 1, g.fh, g.fw);
                 __hip_atomic_store(&tg.counter[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // with exact mode on, the refinement kernel that follows publishes the ticket (the answer may still change)
                 if (tg.done_flag && b == 0) __hip_atomic_store(tg.done_flag, tg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }

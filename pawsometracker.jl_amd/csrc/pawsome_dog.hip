@@ -10,6 +10,7 @@
 #include "dog_roll.hpp"
 #include "dog_twopass.hpp"
 #include "dog_fused.hpp"
+#include "dog_exact.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -53,6 +54,7 @@ int fail(int code, const std::string &msg)
 struct Switches {
     bool host_copy = false, host_sync = false, host_trace = false, twopass_4l = false, hpass16 = false;
     bool ingest_no_nt = false, ingest_trace = false, fused_diag = false;
+    bool no_exact = false;                // PDOG_NO_EXACT: trackers start with exact mode off (A/B of its cost)
     size_t scratch_cap = (size_t)6 << 30; // HBM scratch of the two-pass intermediate; larger batches go in chunks
     int fused_pr = 0, fused_pc = 0;       // PDOG_FUSED_P=pr,pc (0: chosen per geometry)
     int host_threads = 0;                 // PDOG_HOST_THREADS (0: min(16, cores))
@@ -71,6 +73,7 @@ Switches read_switches()
     w.ingest_no_nt = on("PDOG_INGEST_NO_NT");
     w.ingest_trace = on("PDOG_INGEST_TRACE");
     w.fused_diag = on("PDOG_FUSED_DIAG");
+    w.no_exact = on("PDOG_NO_EXACT");
     if (const char *e = std::getenv("PDOG_SCRATCH_MB")) w.scratch_cap = (size_t)std::max(1, std::atoi(e)) << 20;
     if (const char *e = std::getenv("PDOG_FUSED_P")) {
         int a = 0, b = 0;
@@ -220,9 +223,22 @@ struct pdog_tracker {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     f2 *d_taps_row = nullptr, *d_taps_col = nullptr;
     f2 *d_taps_roll = nullptr; // paired column-tap table of dog_roll.hpp
-    float *d_part_val = nullptr;
+    float *d_part_val = nullptr, *d_part_sec = nullptr;
     int *d_part_idx = nullptr;
     int cap_windows = 0;
+    // exact mode (dog_exact.hpp): windows whose two best FP32 responses lie within 2δ are re-decided in the
+    // reference's own Float64 arithmetic
+    bool exact = true;
+    bool exact_all = false;           // pdog_set_exact(t, 2): refine every window with an infinite threshold (tests: the whole reference computation on the device)
+    float exact_T = 0.f;              // 2δ
+    double *d_K64 = nullptr;          // dir·(g₊⊗g₊ − g₋⊗g₋), l×l column-major, Float64 (:41-43)
+    int *d_ref_count = nullptr;       // [1] refine-list length, [1] finished workgroups
+    int *d_ref_list = nullptr;        // [cap] windows
+    float *d_ref_max = nullptr;       // [cap] their FP32 maxima
+    unsigned long long *d_ref_stat = nullptr;
+    double *d_ref_pval = nullptr;     // [cap][nblk] Float64 partial peaks
+    int *d_ref_pidx = nullptr, *d_ref_done = nullptr;
+    int ref_cbw = 1, ref_nblk = 1;
     // host-path staging (pdog_detect_host / chain seed)
     uint8_t *d_frame = nullptr;
     int32_t *d_small = nullptr; // [0..1] guess, [2..3] result
@@ -261,7 +277,7 @@ int choose_variant(pdog_tracker *t, int forced)
         const Variant &v = kVariants[i];
         if (forced >= 0 && v.id != forced) continue;
         if (v.fused) { // never the tracker's batch kernel unless forced; small batches and chains reach it below
-            if (forced == v.id && fused_lds_bytes(t->n1, t->n2, t->L) <= kMaxLds - 1024 && t->n2 + t->L - 1 <= 4 * FUSED_NT && t->fw >= 4) best = &v;
+            if (forced == v.id && fused_lds_bytes(t->n1, t->n2, t->L) <= kMaxLds - 4096 && t->n2 + t->L - 1 <= 4 * FUSED_NT && t->fw >= 4) best = &v;
             continue;
         }
         if (v.LT != 0 && v.LT != t->L) continue;
@@ -294,7 +310,7 @@ int choose_variant(pdog_tracker *t, int forced)
     t->thin_x0 = 0;
     t->forced_variant = forced >= 0;
     t->small_twopass = false;
-    t->fused_ok = fused_lds_bytes(t->n1, t->n2, t->L) <= kMaxLds - 1024 && t->n2 + t->L - 1 <= 4 * FUSED_NT && t->fw >= 4;
+    t->fused_ok = fused_lds_bytes(t->n1, t->n2, t->L) <= kMaxLds - 4096 && t->n2 + t->L - 1 <= 4 * FUSED_NT && t->fw >= 4;
     if (t->fused_ok) {
         for (bool resp : {false, true}) {
             if (int rc = raise_lds_limit((const void *)fused_kernel_for(t->L, resp), fused_lds_bytes(t->n1, t->n2, t->L))) return rc;
@@ -365,13 +381,22 @@ int ensure_capacity(pdog_tracker *t, int n)
     for (int i = 0; i < kNumVariants; ++i)
         if (!kVariants[i].fused) max_strips = std::max(max_strips, (t->n2 + kVariants[i].tw() - 1) / kVariants[i].tw() + kThinMax);
     max_strips = std::max(max_strips, (t->n2 + 7) / 8);
-    if (t->d_part_val) (void)hipFree(t->d_part_val);
-    if (t->d_part_idx) (void)hipFree(t->d_part_idx);
-    t->d_part_val = nullptr;
+    for (void *p : {(void *)t->d_part_val, (void *)t->d_part_idx, (void *)t->d_part_sec, (void *)t->d_ref_list, (void *)t->d_ref_max,
+                    (void *)t->d_ref_pval, (void *)t->d_ref_pidx, (void *)t->d_ref_done})
+        if (p) (void)hipFree(p);
+    t->d_part_val = t->d_part_sec = nullptr;
     t->d_part_idx = nullptr;
+    t->d_ref_list = nullptr; t->d_ref_max = nullptr; t->d_ref_pval = nullptr; t->d_ref_pidx = nullptr; t->d_ref_done = nullptr;
     t->cap_windows = 0;
     HIP_TRY(hipMalloc(&t->d_part_val, sizeof(float) * (size_t)n * max_strips));
+    HIP_TRY(hipMalloc(&t->d_part_sec, sizeof(float) * (size_t)n * max_strips));
     HIP_TRY(hipMalloc(&t->d_part_idx, sizeof(int) * (size_t)n * max_strips));
+    HIP_TRY(hipMalloc(&t->d_ref_list, sizeof(int) * (size_t)n));
+    HIP_TRY(hipMalloc(&t->d_ref_max, sizeof(float) * (size_t)n));
+    HIP_TRY(hipMalloc(&t->d_ref_pval, sizeof(double) * (size_t)n * t->ref_nblk));
+    HIP_TRY(hipMalloc(&t->d_ref_pidx, sizeof(int) * (size_t)n * t->ref_nblk));
+    HIP_TRY(hipMalloc(&t->d_ref_done, sizeof(int) * (size_t)n));
+    HIP_TRY(hipMemset(t->d_ref_done, 0, sizeof(int) * (size_t)n));
     t->cap_windows = n;
     return PDOG_OK;
 }
@@ -397,6 +422,48 @@ int path_for_batch(const pdog_tracker *t, int n)
     if (few && t->fused_ok) return kPathFused;
     if (v.twopass || (few && t->small_twopass)) return kPathTwoPass;
     return v.id;
+}
+
+ExactCtl exact_ctl(const pdog_tracker *t)
+{
+    ExactCtl x;
+    x.count = t->exact ? t->d_ref_count : nullptr;
+    x.list = t->d_ref_list;
+    x.list_max = t->d_ref_max;
+    x.stat = t->d_ref_stat;
+    x.range_err = t->d_mail_map ? t->d_mail_map + 5 : nullptr;
+    x.T = t->exact_all ? __builtin_huge_valf() : t->exact_T;
+    return x;
+}
+
+// The refinement of exact mode (dog_exact.hpp) for the list the kernels of this batch left behind: a persistent grid
+// that exits at once when the list is empty (the usual case).  With done_flag set it also publishes the host
+// functor's ticket once the answer is final.
+constexpr int kRefineGrid = 1024;
+int launch_refine(pdog_tracker *t, const LaunchGeo &g, int32_t *d_out_ij, int32_t *d_done_flag, int32_t done_value)
+{
+    if (!t->exact) return PDOG_OK;
+    RefineGeo rg;
+    rg.g = g;
+    rg.count = t->d_ref_count;
+    rg.list = t->d_ref_list;
+    rg.list_max = t->d_ref_max;
+    rg.T = t->exact_all ? __builtin_huge_valf() : t->exact_T;
+    rg.K64 = t->d_K64;
+    rg.cbw = t->ref_cbw;
+    rg.nblk = t->ref_nblk;
+    rg.part_val = t->d_ref_pval;
+    rg.part_idx = t->d_ref_pidx;
+    rg.part_done = t->d_ref_done;
+    rg.out_ij = d_out_ij;
+    rg.blocks_done = t->d_ref_count + 1;
+    rg.done_flag = d_done_flag;
+    rg.done_value = done_value;
+    const int grid = (int)std::min<long long>(kRefineGrid, (long long)g.n * t->ref_nblk);
+    hipLaunchKernelGGL(dog_refine_kernel, dim3(grid), dim3(REFINE_NT), refine_lds_bytes(t->n1, t->L, t->ref_cbw), t->stream, rg,
+                       (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
+    HIP_TRY(hipGetLastError());
+    return PDOG_OK;
 }
 
 // One workgroup per window (chain_len = 1) or per clip (chain_len frames, frame k > 0 starts at frame k−1's answer).
@@ -440,6 +507,8 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     fg.done_flag = d_done_flag;
     fg.done_value = done_value;
     fg.progress = progress ? 1 : 0;
+    fg.K64 = t->exact ? t->d_K64 : nullptr;
+    g.ex = exact_ctl(t);
     const size_t lds = fused_lds_bytes(t->n1, t->n2, t->L);
     typedef fused_fn_t fused_fn;
     fused_fn fn = fused_kernel_for(t->L, d_out_resp != nullptr);
@@ -472,6 +541,8 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     g.resp = d_out_resp;
     g.part_val = t->d_part_val;
     g.part_idx = t->d_part_idx;
+    g.part_sec = t->d_part_sec;
+    g.ex = exact_ctl(t);
     g.fh = FH; g.fw = FW; g.r1 = t->r1; g.r2 = t->r2; g.n1 = t->n1; g.n2 = t->n2;
     g.L = t->L; g.fill = t->fill; g.nstrips = t->nstrips; g.n = n;
     g.RR = v.ring(t->L);
@@ -539,7 +610,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
             }
             tg.counter = t->d_counter;
             tg.win0 = 0;
-            tg.done_flag = d_done_flag;
+            tg.done_flag = t->exact ? nullptr : d_done_flag; // exact mode: the refinement kernel publishes the ticket (the answer is final only then)
             tg.done_value = done_value;
             if (ticket_armed) *ticket_armed = d_done_flag != nullptr;
             hipLaunchKernelGGL((dog_h1_kernel<13, 8, true>), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
@@ -549,7 +620,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
             else
                 hipLaunchKernelGGL((dog_hpass_kernel<7, 16, false, 8, true>), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             HIP_TRY(hipGetLastError());
-            return PDOG_OK;
+            return launch_refine(t, g, d_out_ij, d_done_flag, done_value);
         }
         hipLaunchKernelGGL(dog_dc_kernel, dim3(n), dim3(64), 0, t->stream, g, t->d_dc);
         HIP_TRY(hipGetLastError());
@@ -570,10 +641,10 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
             HIP_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(dog_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, t->stream,
-                           t->d_part_val, t->d_part_idx, d_guesses, d_out_ij, n, g.nslots,
-                           t->r1, t->r2, t->n1, FH, FW);
+                           t->d_part_val, t->d_part_idx, t->d_part_sec, g.ex, d_guesses, d_out_ij, n, g.nslots,
+                           t->r1, t->r2, t->n1, FH, FW, t->L >> 1);
         HIP_TRY(hipGetLastError());
-        return PDOG_OK;
+        return launch_refine(t, g, d_out_ij, nullptr, 0);
     }
     const int grid = round_up(g.nblocks, 8);
     if (t->nthin) {
@@ -598,10 +669,10 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     HIP_TRY(hipGetLastError());
     if (t->nthin) HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0)); // join before the strip combine
     hipLaunchKernelGGL(dog_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, t->stream,
-                       t->d_part_val, t->d_part_idx, d_guesses, d_out_ij, n, g.nslots,
-                       t->r1, t->r2, t->n1, FH, FW);
+                       t->d_part_val, t->d_part_idx, t->d_part_sec, g.ex, d_guesses, d_out_ij, n, g.nslots,
+                       t->r1, t->r2, t->n1, FH, FW, t->L >> 1);
     HIP_TRY(hipGetLastError());
-    return PDOG_OK;
+    return launch_refine(t, g, d_out_ij, nullptr, 0);
 }
 
 } // namespace
@@ -760,6 +831,29 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
     CREATE_TRY(hipMalloc(&t->d_small, sizeof(int32_t) * 4));
     CREATE_TRY(hipHostMalloc(&t->h_pinned, sizeof(int32_t) * 8, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(t->h_pinned, 0, sizeof(int32_t) * 8);
+    CREATE_TRY(hipHostGetDevicePointer((void **)&t->d_mail_map, t->h_pinned, 0));
+    {
+        // exact mode (dog_exact.hpp): the reference's dense kernel in Float64, built exactly as :41-43 builds it
+        // (K = dir·(g₊⊗g₊ − g₋⊗g₋), column-major), and the decision threshold T = 2δ, δ = u·(6l + 4) for |pixel − dc| ≤ 255
+        std::vector<double> K((size_t)t->L * t->L);
+        const double dir = t->darker ? -1.0 : 1.0;
+        for (int j = 0; j < t->L; ++j)
+            for (int i = 0; i < t->L; ++i) K[i + (size_t)t->L * j] = dir * (gp[i] * gp[j] - gm[i] * gm[j]);
+        CREATE_TRY(hipMalloc(&t->d_K64, sizeof(double) * K.size()));
+        CREATE_TRY(hipMemcpy(t->d_K64, K.data(), sizeof(double) * K.size(), hipMemcpyHostToDevice));
+        const double delta = std::ldexp(1.0, -24) * (6.0 * t->L + 4.0) * 1.02 + 1e-9;
+        t->exact_T = std::nextafter((float)(2.0 * delta), 1.0f);
+        CREATE_TRY(hipMalloc(&t->d_ref_count, sizeof(int) * 2));
+        CREATE_TRY(hipMemset(t->d_ref_count, 0, sizeof(int) * 2));
+        CREATE_TRY(hipMalloc(&t->d_ref_stat, sizeof(unsigned long long)));
+        CREATE_TRY(hipMemset(t->d_ref_stat, 0, sizeof(unsigned long long)));
+        // refinement work items: column blocks whose row-pass result fits ≈20 KB of LDS
+        const int NA = t->n1 + t->L - 1;
+        t->ref_cbw = std::max(1, std::min(8, (int)(20480 / ((size_t)NA * sizeof(f2)))));
+        t->ref_nblk = (t->n2 + t->ref_cbw - 1) / t->ref_cbw;
+        t->exact = !t->sw.no_exact && refine_lds_bytes(t->n1, t->L, 1) <= kMaxLds - 8192;
+        if (raise_lds_limit((const void *)dog_refine_kernel, refine_lds_bytes(t->n1, t->L, t->ref_cbw))) { pdog_destroy(t); return PDOG_E_HIP; }
+    }
 #undef CREATE_TRY
     rc = ensure_capacity(t, 1);
     if (rc) { pdog_destroy(t); return rc; }
@@ -775,8 +869,10 @@ int pdog_destroy(pdog_tracker *t)
     if (t->d_taps_row) (void)hipFree(t->d_taps_row);
     if (t->d_taps_col) (void)hipFree(t->d_taps_col);
     if (t->d_taps_roll) (void)hipFree(t->d_taps_roll);
-    if (t->d_part_val) (void)hipFree(t->d_part_val);
-    if (t->d_part_idx) (void)hipFree(t->d_part_idx);
+    for (void *p : {(void *)t->d_part_val, (void *)t->d_part_idx, (void *)t->d_part_sec, (void *)t->d_ref_list, (void *)t->d_ref_max,
+                    (void *)t->d_ref_pval, (void *)t->d_ref_pidx, (void *)t->d_ref_done, (void *)t->d_K64, (void *)t->d_ref_count,
+                    (void *)t->d_ref_stat})
+        if (p) (void)hipFree(p);
     if (t->d_frame) (void)hipFree(t->d_frame);
     if (t->d_small) (void)hipFree(t->d_small);
     if (t->h_pinned) (void)hipHostFree(t->h_pinned);
@@ -881,6 +977,37 @@ int pdog_sync(pdog_tracker *t)
 {
     if (!t) return fail(PDOG_E_ARG, "pdog_sync: null tracker");
     HIP_TRY(hipStreamSynchronize(t->stream));
+    if (__atomic_load_n(&t->h_pinned[5], __ATOMIC_ACQUIRE)) { // raised by a kernel: a device-resident guess was out of range
+        __atomic_store_n(&t->h_pinned[5], 0, __ATOMIC_RELEASE);
+        return fail(PDOG_E_RANGE, "pdog_sync: a guess of the work just finished lies outside the padded frame (reference: BoundsError, "
+                                  "src/PawsomeTracker.jl:45-46); positions were computed with the fill value there");
+    }
+    return PDOG_OK;
+}
+
+int pdog_set_exact(pdog_tracker *t, int on)
+{
+    if (!t) return fail(PDOG_E_ARG, "pdog_set_exact: null tracker");
+    if (on && refine_lds_bytes(t->n1, t->L, 1) > kMaxLds - 8192)
+        return fail(PDOG_E_ARG, "pdog_set_exact: window too tall for the refinement's LDS block");
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    t->exact = on != 0;
+    t->exact_all = on == 2;
+    return PDOG_OK;
+}
+
+int pdog_get_exact(pdog_tracker *t, int *out_on, double *out_threshold, uint64_t *out_refined)
+{
+    if (!t) return fail(PDOG_E_ARG, "pdog_get_exact: null tracker");
+    if (out_on) *out_on = t->exact ? 1 : 0;
+    if (out_threshold) *out_threshold = t->exact_all ? (double)__builtin_huge_valf() : (double)t->exact_T;
+    if (out_refined) {
+        HIP_TRY(hipSetDevice(t->device));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        unsigned long long v = 0;
+        HIP_TRY(hipMemcpy(&v, t->d_ref_stat, sizeof v, hipMemcpyDeviceToHost));
+        *out_refined = (uint64_t)v;
+    }
     return PDOG_OK;
 }
 
@@ -928,7 +1055,6 @@ int pdog_detect_host(pdog_tracker *t, const uint8_t *h_frame, int64_t row_stride
         if (!t->h_tile) {
             HIP_TRY(hipHostMalloc((void **)&t->h_tile, (size_t)th * pitch, hipHostMallocMapped));
             HIP_TRY(hipHostGetDevicePointer((void **)&t->d_tile_map, t->h_tile, 0));
-            HIP_TRY(hipHostGetDevicePointer((void **)&t->d_mail_map, t->h_pinned, 0));
         }
         uint8_t *d_tile = t->d_tile_map;
         int32_t *d_mail = t->d_mail_map;
@@ -1261,7 +1387,12 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
         cg.start = d_start_guesses;
         cg.out_ij = d_out_ij;
         cg.n_frames = n_frames;
-        const size_t lds = (size_t)chain_strips * roll_lds_bytes(v.LT);
+        g.ex = exact_ctl(t);
+        cg.K64 = t->exact ? t->d_K64 : nullptr;
+        cg.taps_col_plain = t->d_taps_col;
+        // the strips' LDS doubles as the refinement's row-pass block: at least one window column of it must fit
+        const size_t lds = std::max((size_t)chain_strips * roll_lds_bytes(v.LT), refine_lds_bytes(t->n1, t->L, 1));
+        cg.lds_bytes = (int)lds;
         if (int rc = raise_lds_limit((const void *)v.chain, lds)) return rc;
         hipLaunchKernelGGL(v.chain, dim3(n_clips), dim3(64 * chain_strips), lds, t->stream, cg,
                            (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_roll);
