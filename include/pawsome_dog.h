@@ -77,6 +77,10 @@ int pdog_kernel_len(double target_width);
 /* The two normalised 1-D Gaussians whose outer products make Kernel.DoG (:43):
  * which = 0 -> sigma, which = 1 -> sqrt(2) sigma.  out has room for cap doubles. */
 int pdog_gaussian_taps(double target_width, int which, double *out, int cap);
+/* kernel = direction * Kernel.DoG(sigma), src/PawsomeTracker.jl:41-43: the dense l x l Float64 kernel, column-major,
+ * products and difference rounded separately.  This is the table exact mode re-evaluates near-ties with; out has
+ * room for cap (>= l*l) doubles. */
+int pdog_dense_kernel(double target_width, int darker_target, double *out, int cap);
 /* mode(_img), src/PawsomeTracker.jl:47 (StatsBase.mode tie rule: first value whose
  * count exceeds the running maximum while scanning column-major). Host pointer. */
 int pdog_mode_u8(const uint8_t *img, int h, int w, int64_t row_stride, int *out_mode);

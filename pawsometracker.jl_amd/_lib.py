@@ -21,7 +21,7 @@ SYMBOLS = (
     "pdog_alloc_host", "pdog_free_host", "pdog_detect_chain_progress", "pdog_get_stream",
     "pdog_group_create", "pdog_group_destroy", "pdog_group_size", "pdog_group_tracker", "pdog_group_shard",
     "pdog_group_detect_batch", "pdog_group_sync", "pdog_shard_range", "pdog_shard_owner",
-    "pdog_set_exact", "pdog_get_exact",
+    "pdog_set_exact", "pdog_get_exact", "pdog_dense_kernel",
 )
 
 
@@ -47,30 +47,24 @@ _lib = None
 
 
 def _preload_torch_hip_runtime():
-    """PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 (same SONAMEs as /opt/rocm's) and opens them by
-    path.  If this library were loaded first it would bind to /opt/rocm's copies, `import torch` would then bring
-    in a second HIP runtime, and only the runtime initialised first gets the GPU (seen as "no HIP device" from the
-    other).  Loading torch's copies first makes the order irrelevant: one runtime per process, whichever of the
-    two is imported first.  Without torch installed nothing happens and /opt/rocm's runtime is used."""
+    """PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 / librccl (same SONAMEs as /opt/rocm's) and opens
+    them by path.  If this library were loaded first it would bind to /opt/rocm's copies, `import torch` would then
+    bring in a second HIP runtime and a second RCCL, and only the runtime initialised first gets the GPU (seen as
+    "no HIP device" from the other).  So when torch is installed it is imported FIRST: its copies are then the ones
+    in the process and this library's NEEDED entries resolve to them by SONAME.  (Loading torch's libraries one by
+    one instead — as round 1 did for the HIP runtime — breaks their destructor order once librccl is among them:
+    `double free` at interpreter exit.)  Without torch nothing happens and /opt/rocm's libraries are used, as for
+    any C or Julia host."""
     import sys
     if "torch" in sys.modules:
         return
     try:
         import importlib.util
-        spec = importlib.util.find_spec("torch")
-    except (ImportError, ValueError):
+        if importlib.util.find_spec("torch") is None:
+            return
+        import torch  # noqa: F401
+    except (ImportError, ValueError, OSError):
         return
-    if not spec or not spec.origin:
-        return
-    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
-    # librccl too: the library links RCCL for pdog_group_*, and torch ships its own copy (SONAME librccl.so.1)
-    for name in ("libhsa-runtime64.so", "libamdhip64.so", "librccl.so"):
-        path = os.path.join(libdir, name)
-        if os.path.exists(path):
-            try:
-                C.CDLL(path, mode=C.RTLD_GLOBAL)
-            except OSError:
-                return
 
 
 def lib():
@@ -129,6 +123,8 @@ def lib():
         L.pdog_group_sync.restype = i; L.pdog_group_sync.argtypes = [p]
         L.pdog_shard_range.restype = i; L.pdog_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
         L.pdog_shard_owner.restype = i; L.pdog_shard_owner.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
+    if hasattr(L, "pdog_dense_kernel"):
+        L.pdog_dense_kernel.restype = i; L.pdog_dense_kernel.argtypes = [d, i, p, i]
     if hasattr(L, "pdog_set_exact"):
         L.pdog_set_exact.restype = i; L.pdog_set_exact.argtypes = [p, i]
         L.pdog_get_exact.restype = i; L.pdog_get_exact.argtypes = [p, C.POINTER(i), C.POINTER(d), C.POINTER(C.c_uint64)]

@@ -33,11 +33,14 @@
 
 namespace pdog {
 
+#ifndef PDOG_ROLL_LMAX
+#define PDOG_ROLL_LMAX 97
+#endif
 constexpr int ROLL_CH = 8;   // rows per sub-chunk (16 measured equal on cfg3: the kernel is VALU-bound, not latency-bound)
 constexpr int ROLL_P = 8;    // row-pass outputs per lane
 constexpr int ROLL_TW = 64;  // strip width = lanes
 constexpr int ROLL_PR = 65;  // R pitch (f2)
-constexpr int ROLL_LMIN = 17, ROLL_LMAX = 97; // kernel lengths with a roll instance (l = 4m+1).  Up to 97 the l + 7 accumulators and the
+constexpr int ROLL_LMIN = 17, ROLL_LMAX = PDOG_ROLL_LMAX; // kernel lengths with a roll instance (l = 4m+1).  Up to 97 the l + 7 accumulators and the
                                               // row-pass windows fit 256 VGPRs (2 waves per SIMD) with at most a few spills.  l = 101 / 105
                                               // spill 25–70 VGPRs: still 1.25–1.3× the two-pass path in batches, but the persistent chain
                                               // instance for l = 105 returned wrong rows (batch instance correct; not an LDS overrun: the same

@@ -98,11 +98,27 @@ double sigma_of(double tw) { return tw / (2.0 * std::sqrt(2.0 * std::log(2.0)));
 int kernel_len_of_sigma(double s) { return 4 * (int)std::ceil(s * std::sqrt(2.0)) + 1; } // Kernel.DoG
 void gaussian_1d(double s, int l, double *g)
 { // KernelFactors.gaussian: exp(-x²/2σ²) / sum
+#pragma clang fp contract(off)
     const int w = l >> 1;
     for (int x = -w; x <= w; ++x) g[x + w] = std::exp(-((double)x * (double)x) / (2.0 * s * s));
     double sum = 0.0;
     for (int i = 0; i < l; ++i) sum += g[i];
     for (int i = 0; i < l; ++i) g[i] /= sum;
+}
+
+// The reference's dense kernel, K = dir·(g₊⊗g₊ − g₋⊗g₋) (src/PawsomeTracker.jl:41-43), column-major, every product and
+// the difference rounded separately as Julia evaluates them: hipcc contracts a·b − c·d into an FMA by default, which
+// changes last bits — and last bits are exactly what decides the ties exact mode exists for.
+void dense_dog_kernel(const double *gp, const double *gm, int l, bool darker, double *K)
+{
+#pragma clang fp contract(off)
+    const double dir = darker ? -1.0 : 1.0;
+    for (int j = 0; j < l; ++j)
+        for (int i = 0; i < l; ++i) {
+            const double a = gp[i] * gp[j];
+            const double b = gm[i] * gm[j];
+            K[i + (size_t)l * j] = dir * (a - b);
+        }
 }
 
 // MaxDynamicSharedMemorySize is a per-function (per-device) attribute shared by every tracker in the
@@ -698,6 +714,19 @@ int pdog_gaussian_taps(double target_width, int which, double *out, int cap)
     return PDOG_OK;
 }
 
+int pdog_dense_kernel(double target_width, int darker_target, double *out, int cap)
+{
+    if (!out || !(target_width > 0)) return fail(PDOG_E_ARG, "pdog_dense_kernel: bad argument");
+    const double s = sigma_of(target_width);
+    const int l = kernel_len_of_sigma(s);
+    if ((long long)cap < (long long)l * l) return fail(PDOG_E_ARG, "pdog_dense_kernel: buffer too small");
+    std::vector<double> gp(l), gm(l);
+    gaussian_1d(s, l, gp.data());
+    gaussian_1d(s * std::sqrt(2.0), l, gm.data());
+    dense_dog_kernel(gp.data(), gm.data(), l, darker_target != 0, out);
+    return PDOG_OK;
+}
+
 int pdog_mode_u8(const uint8_t *img, int h, int w, int64_t row_stride, int *out_mode)
 {
     if (!img || !out_mode || h <= 0 || w <= 0 || row_stride < w) return fail(PDOG_E_ARG, "pdog_mode_u8: bad argument");
@@ -836,9 +865,7 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
         // exact mode (dog_exact.hpp): the reference's dense kernel in Float64, built exactly as :41-43 builds it
         // (K = dir·(g₊⊗g₊ − g₋⊗g₋), column-major), and the decision threshold T = 2δ, δ = u·(6l + 4) for |pixel − dc| ≤ 255
         std::vector<double> K((size_t)t->L * t->L);
-        const double dir = t->darker ? -1.0 : 1.0;
-        for (int j = 0; j < t->L; ++j)
-            for (int i = 0; i < t->L; ++i) K[i + (size_t)t->L * j] = dir * (gp[i] * gp[j] - gm[i] * gm[j]);
+        dense_dog_kernel(gp.data(), gm.data(), t->L, t->darker != 0, K.data());
         CREATE_TRY(hipMalloc(&t->d_K64, sizeof(double) * K.size()));
         CREATE_TRY(hipMemcpy(t->d_K64, K.data(), sizeof(double) * K.size(), hipMemcpyHostToDevice));
         const double delta = std::ldexp(1.0, -24) * (6.0 * t->L + 4.0) * 1.02 + 1e-9;

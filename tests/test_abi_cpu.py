@@ -158,3 +158,18 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], capture_output=True, text=True, timeout=300)
     assert p.returncode == 2 and f"--gpus {n} requested but only {n - 1} GPU(s) are visible" in p.stderr, (p.returncode, p.stderr[-500:])
     assert p.stdout.strip() == ""
+
+
+def test_dense_kernel_is_bit_equal_to_the_oracle(oracle):
+    """Exact mode re-decides near-ties with the reference's dense Float64 kernel (src/PawsomeTracker.jl:41-43); last
+    bits decide those ties, so the table must equal the oracle's bit for bit (hipcc would contract a*b - c*d into an
+    FMA by default)."""
+    L = pt.lib()
+    for tw in (5, 10, 25, 40, 120):
+        for darker in (0, 1):
+            l = L.pdog_kernel_len(float(tw))
+            K = np.empty((l, l), np.float64, order="F")
+            assert L.pdog_dense_kernel(float(tw), darker, K.ctypes.data, l * l) == 0
+            ref = oracle.dog_kernel(oracle.sigma(tw), bool(darker), l)
+            assert np.array_equal(K.view(np.uint64), ref.view(np.uint64)), (tw, darker)
+    assert L.pdog_dense_kernel(25.0, 1, np.empty(4).ctypes.data, 4) == _lib.PDOG_E_ARG
