@@ -30,32 +30,56 @@ namespace pdog {
 
 typedef const double __attribute__((address_space(4))) *k64_ptr; // uniform Float64 kernel reads → scalar loads
 
-// The reference's value of ONE pixel: dense l×l Float64 correlation around window pixel (y, x) (0-based inside the
-// window), accumulated from 0.0 in kernel column-major order, products and sums rounded separately (:57).
-// lut[p] = p / 255.0 (FixedPointNumbers N0f8 → Float64).  Runs in whatever lanes call it.
+// tmp + a·b with the product and the sum rounded separately (never an FMA): `tmp += a * b` as Julia evaluates it.
+__device__ __forceinline__ double exact_mac(double tmp, double a, double b)
+{
+#pragma clang fp contract(off)
+    const double prod = a * b;
+    return tmp + prod;
+}
+
+// The reference's value of ONE pixel: dense l×l Float64 correlation over the patch whose first pixel is `patch`
+// (rows `pitch` bytes apart), accumulated from 0.0 in kernel column-major order, products and sums rounded separately
+// (:57).  lut[p] = p / 255.0 (FixedPointNumbers N0f8 → Float64).  Runs in whatever lanes call it.  The pixel and
+// table reads of 8 terms are issued together; only the additions form the dependent chain.
+// HIP's __dmul_rn/__dadd_rn are plain operators, and hipcc contracts a·b + c into an FMA by default: exact_mac keeps
+// the product and the sum apart like the reference's `tmp += a*b`.
+template <typename PixelPtr>
+__device__ __forceinline__ double exact_patch(PixelPtr patch, long long pitch, int L, k64_ptr K, const double *lut)
+{
+    double tmp = 0.0;
+    for (int kj = 0; kj < L; ++kj) {
+        const PixelPtr col = patch + kj;
+        const k64_ptr kc = K + (long long)L * kj;
+        int ki = 0;
+        for (; ki + 8 <= L; ki += 8) {
+            double a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = lut[col[(long long)(ki + u) * pitch]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tmp = exact_mac(tmp, a[u], kc[ki + u]);
+        }
+        for (; ki < L; ++ki) tmp = exact_mac(tmp, lut[col[(long long)ki * pitch]], kc[ki]);
+    }
+    return tmp;
+}
+// The same for a patch read from the frame itself (no staged tile): PaddedView semantics (:48) per pixel when the patch
+// leaves the frame.  (i0, j0): 0-based frame coordinates of the patch's first row / column.
 __device__ __forceinline__ double exact_pixel(const uint8_t *__restrict__ frame, long long row_stride, int fh, int fw, int fill,
                                               int i0, int j0, int L, k64_ptr K, const double *lut)
 {
-    // (i0, j0): 0-based frame coordinates of the patch's first row / column (may lie outside the frame)
+    if (i0 >= 0 && i0 + L <= fh && j0 >= 0 && j0 + L <= fw)
+        return exact_patch(frame + (long long)i0 * row_stride + j0, row_stride, L, K, lut);
     double tmp = 0.0;
-    if (i0 >= 0 && i0 + L <= fh && j0 >= 0 && j0 + L <= fw) {
-        const uint8_t *p0 = frame + (long long)i0 * row_stride + j0;
-        for (int kj = 0; kj < L; ++kj) {
-            const uint8_t *p = p0 + kj;
-            const k64_ptr kc = K + (long long)L * kj;
-            for (int ki = 0; ki < L; ++ki) tmp = __dadd_rn(tmp, __dmul_rn(lut[p[(long long)ki * row_stride]], kc[ki]));
-        }
-    } else {
-        for (int kj = 0; kj < L; ++kj) {
-            const int gj = j0 + kj;
-            const bool colok = gj >= 0 && gj < fw;
-            const k64_ptr kc = K + (long long)L * kj;
-            for (int ki = 0; ki < L; ++ki) {
-                const int gi = i0 + ki;
-                int px = fill; // PaddedView, :48
-                if (colok && gi >= 0 && gi < fh) px = frame[(long long)gi * row_stride + gj];
-                tmp = __dadd_rn(tmp, __dmul_rn(lut[px], kc[ki]));
-            }
+    for (int kj = 0; kj < L; ++kj) {
+        const int gj = j0 + kj;
+        const bool colok = gj >= 0 && gj < fw;
+        const k64_ptr kc = K + (long long)L * kj;
+        for (int ki = 0; ki < L; ++ki) {
+            const int gi = i0 + ki;
+            int px = fill; // PaddedView, :48
+            if (colok && gi >= 0 && gi < fh) px = frame[(long long)gi * row_stride + gj];
+            tmp = exact_mac(tmp, lut[px], kc[ki]);
         }
     }
     return tmp;
@@ -80,16 +104,30 @@ __device__ __forceinline__ void peak64_wave_reduce(Peak64 &p)
 
 // ---- refinement of window columns [x0, x0 + ncol) by one workgroup of NT threads (a multiple of 64) ----
 // A deliberately plain separable FP32 evaluation (any evaluation within δ serves: see the header), then the
-// reference's arithmetic for the candidates.  Rlds: NA·ncol f2; lut: 256 doubles; ired/dred: NT/64 entries each.
-// Returns the block's Float64 peak in thread 0 (best = −inf if the block holds no candidate).
+// reference's arithmetic for the candidates.  Rlds: NA·ncol f2; tile: NULL, or NA rows of refine_tile_pitch(ncol, L)
+// bytes — the block's pixels with the PaddedView fill materialised, which both passes then read instead of the
+// frame (a candidate's 4225-term chain must not wait for memory 4225 times); lut: 256 doubles; ired/dred: NT/64
+// entries each.  Returns the block's Float64 peak in thread 0 (best = −inf if the block holds no candidate).
+__host__ __device__ constexpr int refine_tile_pitch(int ncol, int L) { return (ncol + L - 1 + 3) / 4 * 4; }
 __device__ __forceinline__ Peak64 refine_columns(const int NT, const LaunchGeo &g, const uint8_t *__restrict__ frame, int g1, int g2, int x0, int ncol,
-                                                 float thr, tap_ptr trow, tap_ptr tcol, k64_ptr K, f2 *Rlds, double *lut, int *ired, double *dred, bool fill_lut = true)
+                                                 float thr, tap_ptr trow, tap_ptr tcol, k64_ptr K, f2 *Rlds, uint8_t *tile, double *lut, int *ired,
+                                                 double *dred, bool fill_lut = true)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = NT / 64;
     const int L = g.L, hw = L >> 1, NA = g.n1 + L - 1;
     const int ti0 = g1 - g.r1 - 1 - hw, wj0 = g2 - g.r2 - 1 - hw;
+    const int tp = refine_tile_pitch(ncol, L), tw = ncol + L - 1;
     if (fill_lut)
         for (int p = tid; p < 256; p += NT) lut[p] = (double)p / 255.0;
+    if (tile) {
+        for (int e = tid; e < NA * tw; e += NT) {
+            const int a = e / tw, c = e - a * tw;
+            const int gi = ti0 + a, gj = wj0 + x0 + c;
+            int px = g.fill;
+            if (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) px = frame[(long long)gi * g.row_stride + gj];
+            tile[a * tp + c] = (uint8_t)px;
+        }
+    }
     // DC level: the same fixed sample grid as the main kernels (any level in 0…255 keeps the bound)
     int sum = dc_sample_sum(g, frame, ti0, wj0, L, tid, NT);
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
@@ -102,15 +140,20 @@ __device__ __forceinline__ Peak64 refine_columns(const int NT, const LaunchGeo &
     // row pass: R±[a][x] = Σ_k ĝ±[k]·(pixel[a][x0+x+k] − dc), k ascending
     for (int e = tid; e < NA * ncol; e += NT) {
         const int a = e / ncol, x = e - a * ncol;
-        const int gi = ti0 + a, gj0 = wj0 + x0 + x;
-        const bool rowok = gi >= 0 && gi < g.fh;
-        const uint8_t *src = frame + (long long)gi * g.row_stride;
         f2 acc = f2{0.f, 0.f};
-        for (int k = 0; k < L; ++k) {
-            const int gj = gj0 + k;
-            int px = g.fill;
-            if (rowok && gj >= 0 && gj < g.fw) px = src[gj];
-            acc = fma_bcast((float)(px - dc), trow[k], acc);
+        if (tile) {
+            const uint8_t *src = tile + a * tp + x;
+            for (int k = 0; k < L; ++k) acc = fma_bcast((float)((int)src[k] - dc), trow[k], acc);
+        } else {
+            const int gi = ti0 + a, gj0 = wj0 + x0 + x;
+            const bool rowok = gi >= 0 && gi < g.fh;
+            const uint8_t *src = frame + (long long)gi * g.row_stride;
+            for (int k = 0; k < L; ++k) {
+                const int gj = gj0 + k;
+                int px = g.fill;
+                if (rowok && gj >= 0 && gj < g.fw) px = src[gj];
+                acc = fma_bcast((float)(px - dc), trow[k], acc);
+            }
         }
         Rlds[e] = acc;
     }
@@ -129,7 +172,8 @@ __device__ __forceinline__ Peak64 refine_columns(const int NT, const LaunchGeo &
             acc = __builtin_fmaf(r.y, w.y, acc);
         }
         if (acc >= thr) {
-            const double F = exact_pixel(frame, g.row_stride, g.fh, g.fw, g.fill, ti0 + y, wj0 + x0 + x, L, K, lut);
+            const double F = tile ? exact_patch((const uint8_t *)(tile + y * tp + x), (long long)tp, L, K, lut)
+                                  : exact_pixel(frame, g.row_stride, g.fh, g.fw, g.fill, ti0 + y, wj0 + x0 + x, L, K, lut);
             peak64_push(pk, F, (x0 + x) * g.n1 + y);
         }
     }
@@ -152,6 +196,7 @@ struct RefineGeo {
     float T;
     const double *K64;           // l×l, column-major, dir·(g₊⊗g₊ − g₋⊗g₋) (:41-43)
     int cbw, nblk;               // window columns per work item; work items per window
+    int use_tile;                // the block's pixels are staged in LDS behind the row-pass block
     double *part_val;            // [cap][nblk]
     int *part_idx;               // [cap][nblk]
     int *part_done;              // [cap] zero between launches
@@ -162,7 +207,12 @@ struct RefineGeo {
 };
 
 constexpr int REFINE_NT = 256;
-__host__ __device__ constexpr size_t refine_lds_bytes(int n1, int L, int cbw) { return (size_t)(n1 + L - 1) * cbw * sizeof(f2); }
+__host__ __device__ constexpr size_t refine_r_bytes(int n1, int L, int cbw) { return ((size_t)(n1 + L - 1) * cbw * sizeof(f2) + 15) / 16 * 16; }
+__host__ __device__ constexpr size_t refine_tile_bytes(int n1, int L, int cbw) { return (size_t)(n1 + L - 1) * refine_tile_pitch(cbw, L); }
+__host__ __device__ constexpr size_t refine_lds_bytes(int n1, int L, int cbw, bool tile = false)
+{
+    return refine_r_bytes(n1, L, cbw) + (tile ? refine_tile_bytes(n1, L, cbw) : 0);
+}
 
 static __global__ __launch_bounds__(REFINE_NT) void dog_refine_kernel(const RefineGeo rg, const f2 *__restrict__ taps_row,
                                                                       const f2 *__restrict__ taps_col)
@@ -187,7 +237,7 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_refine_kernel(const Refi
         const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
         const int x0 = cb * rg.cbw, ncol = min(rg.cbw, g.n2 - x0);
         Peak64 pk = refine_columns(NT, g, frame, g1, g2, x0, ncol, thr, as_taps(taps_row), as_taps(taps_col), (k64_ptr)(unsigned long long)rg.K64,
-                                       Rlds, lut, ired, dred);
+                                       Rlds, rg.use_tile ? smem + refine_r_bytes(g.n1, g.L, rg.cbw) : nullptr, lut, ired, dred);
         if (tid == 0) {
             __hip_atomic_store(&rg.part_val[(long long)e * rg.nblk + cb], pk.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&rg.part_idx[(long long)e * rg.nblk + cb], pk.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

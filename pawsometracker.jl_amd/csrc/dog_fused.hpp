@@ -327,7 +327,15 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
                     for (int kj = 0; kj < L; ++kj) {
                         const float *col = A + y * fg.pitchA + x + kj;
                         const k64_ptr kc = K + (long long)L * kj;
-                        for (int ki = 0; ki < L; ++ki) tmp = __dadd_rn(tmp, __dmul_rn(s_lut[(int)col[ki * fg.pitchA] + dc], kc[ki]));
+                        int ki = 0;
+                        for (; ki + 8 <= L; ki += 8) { // the 8 tile and table reads go out together; only the additions are a chain
+                            double a8[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) a8[u] = s_lut[(int)col[(ki + u) * fg.pitchA] + dc];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) tmp = exact_mac(tmp, a8[u], kc[ki + u]);
+                        }
+                        for (; ki < L; ++ki) tmp = exact_mac(tmp, s_lut[(int)col[ki * fg.pitchA] + dc], kc[ki]);
                     }
                     peak64_push(p64, tmp, e);
                 }

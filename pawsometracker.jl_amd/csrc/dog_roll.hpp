@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
 struct ChainGeo {
     LaunchGeo g;                         // frames = first frame of clip 0; guesses/frame_index unused
     const double *K64;                   // the reference's dense Float64 kernel (exact mode; null = off), dog_exact.hpp
-    int lds_bytes;                       // dynamic LDS of the workgroup (the refinement's scratch)
+    int ref_cbw, ref_tile;               // refinement inside the kernel: window columns per block; pixel tile staged in LDS (the strips' LDS is its scratch)
     const f2 *taps_col_plain;            // (s·g₊[k], −s·g₋[k]) per tap: the refinement's column taps (taps_col is the roll kernel's paired table)
     const int *__restrict__ start;       // n_clips x 2, 1-based (row, col)
     int *__restrict__ out_ij;            // n_clips x n_frames x 2
@@ -478,15 +478,15 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
         if (s_refine) {
             // near-tie: the chain cannot go on before the reference's own arithmetic has decided (dog_exact.hpp);
             // the strips' LDS is free between frames and holds the row-pass block
-            const int NA = g.n1 + LT - 1;
-            const int cbw = max(1, min(g.n2, cg.lds_bytes / (NA * (int)sizeof(f2))));
+            const int cbw = cg.ref_cbw;
             Peak64 wk;
             wk.best = -__builtin_huge_val();
             wk.idx = 0x7fffffff;
             for (int x0 = 0; x0 < g.n2; x0 += cbw) {
                 const Peak64 bk = refine_columns(blockDim.x, g, frame, g1, g2, x0, min(cbw, g.n2 - x0), s_max - g.ex.T, as_taps(taps_row),
                                                  as_taps(cg.taps_col_plain), (k64_ptr)(unsigned long long)cg.K64,
-                                                 reinterpret_cast<f2 *>(smem), lut, ired, dred, false);
+                                                 reinterpret_cast<f2 *>(smem), cg.ref_tile ? smem + refine_r_bytes(g.n1, LT, cbw) : nullptr, lut, ired,
+                                                 dred, false);
                 if (tid == 0) peak64_push(wk, bk.best, bk.idx);
             }
             if (tid == 0) {

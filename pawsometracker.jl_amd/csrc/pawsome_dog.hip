@@ -255,6 +255,7 @@ struct pdog_tracker {
     double *d_ref_pval = nullptr;     // [cap][nblk] Float64 partial peaks
     int *d_ref_pidx = nullptr, *d_ref_done = nullptr;
     int ref_cbw = 1, ref_nblk = 1;
+    bool ref_tile = false;            // the refinement kernel stages its block's pixels in LDS
     // host-path staging (pdog_detect_host / chain seed)
     uint8_t *d_frame = nullptr;
     int32_t *d_small = nullptr; // [0..1] guess, [2..3] result
@@ -468,6 +469,7 @@ int launch_refine(pdog_tracker *t, const LaunchGeo &g, int32_t *d_out_ij, int32_
     rg.K64 = t->d_K64;
     rg.cbw = t->ref_cbw;
     rg.nblk = t->ref_nblk;
+    rg.use_tile = t->ref_tile ? 1 : 0;
     rg.part_val = t->d_ref_pval;
     rg.part_idx = t->d_ref_pidx;
     rg.part_done = t->d_ref_done;
@@ -476,7 +478,7 @@ int launch_refine(pdog_tracker *t, const LaunchGeo &g, int32_t *d_out_ij, int32_
     rg.done_flag = d_done_flag;
     rg.done_value = done_value;
     const int grid = (int)std::min<long long>(kRefineGrid, (long long)g.n * t->ref_nblk);
-    hipLaunchKernelGGL(dog_refine_kernel, dim3(grid), dim3(REFINE_NT), refine_lds_bytes(t->n1, t->L, t->ref_cbw), t->stream, rg,
+    hipLaunchKernelGGL(dog_refine_kernel, dim3(grid), dim3(REFINE_NT), refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_tile), t->stream, rg,
                        (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
     HIP_TRY(hipGetLastError());
     return PDOG_OK;
@@ -879,7 +881,10 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
         t->ref_cbw = std::max(1, std::min(8, (int)(20480 / ((size_t)NA * sizeof(f2)))));
         t->ref_nblk = (t->n2 + t->ref_cbw - 1) / t->ref_cbw;
         t->exact = !t->sw.no_exact && refine_lds_bytes(t->n1, t->L, 1) <= kMaxLds - 8192;
-        if (raise_lds_limit((const void *)dog_refine_kernel, refine_lds_bytes(t->n1, t->L, t->ref_cbw))) { pdog_destroy(t); return PDOG_E_HIP; }
+        // the block's pixels go to LDS too when they fit beside the row-pass block (l ≲ 120): a candidate's chain then
+        // reads LDS instead of waiting for memory once per term
+        t->ref_tile = refine_lds_bytes(t->n1, t->L, t->ref_cbw, true) <= 64 * 1024;
+        if (raise_lds_limit((const void *)dog_refine_kernel, refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_tile))) { pdog_destroy(t); return PDOG_E_HIP; }
     }
 #undef CREATE_TRY
     rc = ensure_capacity(t, 1);
@@ -1417,9 +1422,10 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
         g.ex = exact_ctl(t);
         cg.K64 = t->exact ? t->d_K64 : nullptr;
         cg.taps_col_plain = t->d_taps_col;
-        // the strips' LDS doubles as the refinement's row-pass block: at least one window column of it must fit
-        const size_t lds = std::max((size_t)chain_strips * roll_lds_bytes(v.LT), refine_lds_bytes(t->n1, t->L, 1));
-        cg.lds_bytes = (int)lds;
+        // the strips' LDS doubles as the refinement's scratch (row-pass block + pixel tile when they fit in 64 KB)
+        cg.ref_cbw = std::min(t->n2, t->ref_cbw);
+        cg.ref_tile = t->ref_tile ? 1 : 0;
+        const size_t lds = std::max((size_t)chain_strips * roll_lds_bytes(v.LT), refine_lds_bytes(t->n1, t->L, cg.ref_cbw, t->ref_tile));
         if (int rc = raise_lds_limit((const void *)v.chain, lds)) return rc;
         hipLaunchKernelGGL(v.chain, dim3(n_clips), dim3(64 * chain_strips), lds, t->stream, cg,
                            (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_roll);
