@@ -187,22 +187,22 @@ __device__ __forceinline__ Peak64 refine_columns(const int NT, const LaunchGeo &
     return pk;
 }
 
-// ---- batch refinement: a persistent grid walks the refine list the main kernels left behind ----
-struct RefineGeo {
-    LaunchGeo g;                 // frames, strides, frame_index, guesses, geometry (part_* unused)
-    int *count;                  // length of the refine list; reset by the last workgroup to finish
-    const int *list;
-    const float *list_max;
-    float T;
-    const double *K64;           // l×l, column-major, dir·(g₊⊗g₊ − g₋⊗g₋) (:41-43)
-    int cbw, nblk;               // window columns per work item; work items per window
+// ---- the last kernel of a batch: strip combine + index map + clamp (:58-61), and the refinement of exact mode ----
+// S workgroups per window.  Every one of them combines the window's partial peaks (a handful of loads); part 0
+// writes the FP32 answer, checks the guess's range and — the usual case — that is all: the runner-up lies further
+// than 2δ below the maximum.  Otherwise the S workgroups share the window's column blocks, re-evaluate the
+// near-maximal pixels in the reference's arithmetic, and the last one to finish writes the reference's answer.
+struct FinishGeo {
+    LaunchGeo g;                 // frames, strides, frame_index, guesses, geometry, part_val/idx/sec, nslots, ex
+    const double *K64;           // l×l, column-major, dir·(g₊⊗g₊ − g₋⊗g₋) (:41-43); null = exact mode off
+    int cbw, nblk;               // window columns per column block; column blocks per window
     int use_tile;                // the block's pixels are staged in LDS behind the row-pass block
-    double *part_val;            // [cap][nblk]
-    int *part_idx;               // [cap][nblk]
-    int *part_done;              // [cap] zero between launches
-    int32_t *out_ij;             // [n][2] positions to overwrite
-    int *blocks_done;            // [1] zero between launches: workgroups that have finished (the last one resets the list and publishes)
-    int32_t *done_flag;          // NULL or host-coherent ticket word (see dog_fused.hpp)
+    int S;                       // workgroups per window
+    double *part_val;            // [n][S] Float64 partial peaks
+    int *part_idx;               // [n][S]
+    int *part_done;              // [n] zero between launches
+    int32_t *out_ij;             // [n][2]
+    int32_t *done_flag;          // NULL or host-coherent ticket word (see dog_fused.hpp): published with window 0's final answer
     int32_t done_value;
 };
 
@@ -214,7 +214,7 @@ __host__ __device__ constexpr size_t refine_lds_bytes(int n1, int L, int cbw, bo
     return refine_r_bytes(n1, L, cbw) + (tile ? refine_tile_bytes(n1, L, cbw) : 0);
 }
 
-static __global__ __launch_bounds__(REFINE_NT) void dog_refine_kernel(const RefineGeo rg, const f2 *__restrict__ taps_row,
+static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const FinishGeo fg, const f2 *__restrict__ taps_row,
                                                                       const f2 *__restrict__ taps_col)
 {
     constexpr int NT = REFINE_NT, NW = NT / 64;
@@ -222,54 +222,64 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_refine_kernel(const Refi
     __shared__ double lut[256];
     __shared__ double dred[NW];
     __shared__ int ired[NW];
-    __shared__ int s_last;
-    const LaunchGeo &g = rg.g;
-    f2 *Rlds = reinterpret_cast<f2 *>(smem);
+    __shared__ int s_refine, s_last;
+    __shared__ float s_max;
+    const LaunchGeo &g = fg.g;
     const int tid = threadIdx.x;
-    const int n = __hip_atomic_load(rg.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long items = (long long)n * rg.nblk;
-    for (long long item = blockIdx.x; item < items; item += gridDim.x) {
-        const int e = (int)(item / rg.nblk), cb = (int)(item - (long long)e * rg.nblk);
-        const int b = rg.list[e];
-        const float thr = rg.list_max[e] - rg.T;
-        const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
-        const int fidx = g.frame_index ? g.frame_index[b] : b;
-        const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
-        const int x0 = cb * rg.cbw, ncol = min(rg.cbw, g.n2 - x0);
-        Peak64 pk = refine_columns(NT, g, frame, g1, g2, x0, ncol, thr, as_taps(taps_row), as_taps(taps_col), (k64_ptr)(unsigned long long)rg.K64,
-                                       Rlds, rg.use_tile ? smem + refine_r_bytes(g.n1, g.L, rg.cbw) : nullptr, lut, ired, dred);
-        if (tid == 0) {
-            __hip_atomic_store(&rg.part_val[(long long)e * rg.nblk + cb], pk.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&rg.part_idx[(long long)e * rg.nblk + cb], pk.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int old = __hip_atomic_fetch_add(&rg.part_done[e], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = (old == rg.nblk - 1);
+    const int b = blockIdx.x / fg.S, part = blockIdx.x - b * fg.S;
+    const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
+    if (tid == 0) {
+        Peak pk;
+        peak_init(pk);
+        for (int s = 0; s < g.nslots; ++s) peak_merge(pk, g.part_val[b * g.nslots + s], g.part_idx[b * g.nslots + s], g.part_sec[b * g.nslots + s]);
+        const bool rf = fg.K64 && (pk.best - pk.second <= g.ex.T);
+        if (part == 0) {
+            range_check(g.ex, g1, g2, g.L >> 1, g.fh, g.fw);
+            if (rf) {
+                atomicAdd(g.ex.stat, 1ull);
+            } else {
+                const int x = pk.idx / g.n1, y = pk.idx - x * g.n1;
+                fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);       // :60-61
+                fg.out_ij[2 * b + 1] = min(max(g2 - g.r2 + x, 1), g.fw);
+                if (fg.done_flag && b == 0) __hip_atomic_store(fg.done_flag, fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
-        __syncthreads();
-        if (s_last && tid == 0) { // this window's last block: first Float64 maximum over its blocks → position (:59-61)
+        s_refine = rf;
+        s_max = pk.best;
+    }
+    __syncthreads();
+    if (!s_refine) return;
+    const int fidx = g.frame_index ? g.frame_index[b] : b;
+    const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
+    const float thr = s_max - g.ex.T;
+    Peak64 mine;
+    mine.best = -__builtin_huge_val();
+    mine.idx = 0x7fffffff;
+    for (int cb = part; cb < fg.nblk; cb += fg.S) {
+        const int x0 = cb * fg.cbw, ncol = min(fg.cbw, g.n2 - x0);
+        const Peak64 pk = refine_columns(NT, g, frame, g1, g2, x0, ncol, thr, as_taps(taps_row), as_taps(taps_col), (k64_ptr)(unsigned long long)fg.K64,
+                                         reinterpret_cast<f2 *>(smem), fg.use_tile ? smem + refine_r_bytes(g.n1, g.L, fg.cbw) : nullptr, lut, ired, dred);
+        if (tid == 0) peak64_push(mine, pk.best, pk.idx);
+    }
+    if (tid == 0) {
+        __hip_atomic_store(&fg.part_val[(long long)b * fg.S + part], mine.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&fg.part_idx[(long long)b * fg.S + part], mine.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int old = __hip_atomic_fetch_add(&fg.part_done[b], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old == fg.S - 1);
+        if (s_last) { // this window's last workgroup: first Float64 maximum over all of them → position (:59-61)
             Peak64 w;
             w.best = -__builtin_huge_val();
             w.idx = 0x7fffffff;
-            for (int k = 0; k < rg.nblk; ++k)
-                peak64_push(w, __hip_atomic_load(&rg.part_val[(long long)e * rg.nblk + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                            __hip_atomic_load(&rg.part_idx[(long long)e * rg.nblk + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            for (int k = 0; k < fg.S; ++k)
+                peak64_push(w, __hip_atomic_load(&fg.part_val[(long long)b * fg.S + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                            __hip_atomic_load(&fg.part_idx[(long long)b * fg.S + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             const int x = w.idx / g.n1, y = w.idx - x * g.n1;
-            rg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);
-            rg.out_ij[2 * b + 1] = min(max(g2 - g.r2 + x, 1), g.fw);
-            __hip_atomic_store(&rg.part_done[e], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-    }
-    // the last workgroup through leaves the list empty for the next call and, for the single-window host functor,
-    // publishes the ticket (the answer is final only now)
-    if (tid == 0) {
-        __threadfence();
-        const int old = __hip_atomic_fetch_add(rg.blocks_done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == (int)gridDim.x - 1) {
-            __hip_atomic_store(rg.blocks_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(rg.count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (rg.done_flag) {
+            fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);
+            fg.out_ij[2 * b + 1] = min(max(g2 - g.r2 + x, 1), g.fw);
+            __hip_atomic_store(&fg.part_done[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (fg.done_flag && b == 0) {
                 __threadfence_system();
-                __hip_atomic_store(rg.done_flag, rg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(fg.done_flag, fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }

@@ -71,26 +71,13 @@ __device__ __forceinline__ void peak_wave_reduce(Peak &p, int width = 64)
     }
 }
 
-// What the main kernels hand to the refinement (dog_exact.hpp): windows whose two best FP32 responses lie within
-// T = 2δ of each other are listed for a Float64 re-evaluation of their near-maximal pixels.
+// Exact mode (dog_exact.hpp): a window whose two best FP32 responses lie within T = 2δ of each other is re-decided
+// by a Float64 re-evaluation of its near-maximal pixels.
 struct ExactCtl {
-    int *count;               // [1] length of the refine list (the refinement kernel leaves it at zero); null = exact mode off
-    int *list;                // [cap] windows to refine
-    float *list_max;          // [cap] their FP32 maxima
-    unsigned long long *stat; // [1] windows listed since the tracker was created (diagnostics)
+    unsigned long long *stat; // [1] windows re-evaluated since the tracker was created (diagnostics)
     int *range_err;           // host-coherent word: set when a guess lies where the reference raises BoundsError (:45-46)
     float T;                  // 2δ
 };
-// one thread, after a window's partials have been combined
-__device__ __forceinline__ void exact_flag(const ExactCtl &x, int b, float best, float second)
-{
-    if (x.count && best - second <= x.T) {
-        const int k = atomicAdd(x.count, 1);
-        x.list[k] = b;
-        x.list_max[k] = best;
-        atomicAdd(x.stat, 1ull);
-    }
-}
 // The reference's PaddedView extends radii + l past the frame (:45-46) and the filter reads radii + l÷2 around the
 // guess: a guess outside [−l÷2, sz + l÷2 + 1] raises BoundsError there.  Device-resident guesses cannot be checked
 // before the launch, so the kernels raise a flag that pdog_sync reports.
@@ -449,30 +436,6 @@ __global__ __launch_bounds__(NT, 2) void dog_window_kernel(const LaunchGeo g, co
         g.part_idx[b * g.nslots + s] = pk.idx;
         g.part_sec[b * g.nslots + s] = pk.second;
     }
-}
-
-// Combine the strips of each window, map window-local → absolute, clamp
-// (src/PawsomeTracker.jl:60-61).  One thread per window.
-static __global__ void dog_finalize_kernel(const float *__restrict__ part_val, const int *__restrict__ part_idx,
-                                           const float *__restrict__ part_sec, const ExactCtl ex,
-                                           const int *__restrict__ guesses, int *__restrict__ out_ij,
-                                           int n, int nstrips, int r1, int r2, int n1, int fh, int fw, int hw)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n) return;
-    Peak pk;
-    peak_init(pk);
-    for (int s = 0; s < nstrips; ++s) peak_merge(pk, part_val[b * nstrips + s], part_idx[b * nstrips + s], part_sec[b * nstrips + s]);
-    exact_flag(ex, b, pk.best, pk.second);
-    range_check(ex, guesses[2 * b], guesses[2 * b + 1], hw, fh, fw);
-    const int idx = pk.idx;
-    const int x = idx / n1, y = idx - x * n1;
-    int i = guesses[2 * b] - r1 + y;
-    int j = guesses[2 * b + 1] - r2 + x;
-    i = min(max(i, 1), fh);
-    j = min(max(j, 1), fw);
-    out_ij[2 * b] = i;
-    out_ij[2 * b + 1] = j;
 }
 
 // mode(_img), src/PawsomeTracker.jl:47, for a frame that already lives on the device.  StatsBase.mode keeps

@@ -34,17 +34,16 @@
 namespace pdog {
 
 #ifndef PDOG_ROLL_LMAX
-#define PDOG_ROLL_LMAX 97
+#define PDOG_ROLL_LMAX 105
 #endif
 constexpr int ROLL_CH = 8;   // rows per sub-chunk (16 measured equal on cfg3: the kernel is VALU-bound, not latency-bound)
 constexpr int ROLL_P = 8;    // row-pass outputs per lane
 constexpr int ROLL_TW = 64;  // strip width = lanes
 constexpr int ROLL_PR = 65;  // R pitch (f2)
 constexpr int ROLL_LMIN = 17, ROLL_LMAX = PDOG_ROLL_LMAX; // kernel lengths with a roll instance (l = 4m+1).  Up to 97 the l + 7 accumulators and the
-                                              // row-pass windows fit 256 VGPRs (2 waves per SIMD) with at most a few spills.  l = 101 / 105
-                                              // spill 25–70 VGPRs: still 1.25–1.3× the two-pass path in batches, but the persistent chain
-                                              // instance for l = 105 returned wrong rows (batch instance correct; not an LDS overrun: the same
-                                              // with 1 KB of LDS padding around every wave) — not shipped
+                                              // row-pass windows fit 256 VGPRs (2 waves per SIMD); l = 101 / 105 spill 37–52 VGPRs inside the
+                                              // loop and are still faster than the two-pass path in batches (see roll_strip_call for what
+                                              // round 1's wrong rows at l = 105 led to)
 
 // accumulator slots: the l outputs in flight plus the sub-chunk being emitted, rounded so that the
 // slot ↔ tap mapping repeats after a whole number of sub-chunks
@@ -393,6 +392,32 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
 }
 
 
+// The strip as an out-of-line function with a register allocation of its own.  The persistent chain kernel calls it
+// (inlined into that kernel's frame loop the accumulators, the row-pass windows and the loop state did not fit:
+// 18–64 VGPRs went to scratch inside the hot loop, and the l = 105 instance returned wrong rows in round 1 while
+// the batch kernel of the same length, compiled separately, was correct); so do the batch kernels of the longest
+// instances, so that batch and chain run the SAME machine code there.  Arguments arrive in VGPRs by the calling
+// convention: everything uniform goes back to SGPRs with readfirstlane (tap tables are read with scalar loads).
+__device__ __forceinline__ unsigned long long uniform_u64(const void *p)
+{
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int LT>
+__device__ __attribute__((noinline)) void roll_strip_call(const LaunchGeo *gp, const f2 *taps_row, const f2 *taps_col, unsigned char *smem,
+                                                          const uint8_t *frame, int g1, int g2, int s, int b, Peak *out)
+{
+    LaunchGeo g;
+    __builtin_memcpy(&g, (const void *)uniform_u64(gp), sizeof g);
+    Peak pk;
+    roll_strip<LT, false, 0>(g, (const f2 *)uniform_u64(taps_row), (const f2 *)uniform_u64(taps_col), smem, (const uint8_t *)uniform_u64(frame),
+                             __builtin_amdgcn_readfirstlane(g1), __builtin_amdgcn_readfirstlane(g2), __builtin_amdgcn_readfirstlane(s),
+                             __builtin_amdgcn_readfirstlane(b), 0, pk);
+    *out = pk;
+}
+constexpr int ROLL_CALL_LMIN = 101; // batch kernels from this length on run the out-of-line strip too
+
 template <int LT, bool RESP, int ABL = 0>
 __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, const f2 *__restrict__ taps_row,
                                                          const f2 *__restrict__ taps_col)
@@ -408,7 +433,10 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
     const int fidx = g.frame_index ? g.frame_index[b] : b;
     const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
     Peak pk;
-    roll_strip<LT, RESP, ABL>(g, taps_row, taps_col, smem, frame, g1, g2, s, b, logical, pk);
+    if constexpr (LT >= ROLL_CALL_LMIN && !RESP && ABL == 0)
+        roll_strip_call<LT>(&g, taps_row, taps_col, smem, frame, g1, g2, s, b, &pk);
+    else
+        roll_strip<LT, RESP, ABL>(g, taps_row, taps_col, smem, frame, g1, g2, s, b, logical, pk);
     if (threadIdx.x == 0) {
         g.part_val[b * g.nslots + s] = pk.best;
         g.part_idx[b * g.nslots + s] = pk.idx;
@@ -457,7 +485,7 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
         const int g1 = cur[0], g2 = cur[1];
         const uint8_t *__restrict__ frame = g.frames + ((long long)c * cg.n_frames + k) * g.frame_stride;
         Peak pk;
-        roll_strip<LT, false, 0>(g, taps_row, taps_col, smem + wave * roll_lds_bytes(LT), frame, g1, g2, wave, 0, 0, pk);
+        roll_strip_call<LT>(&g, taps_row, taps_col, smem + wave * roll_lds_bytes(LT), frame, g1, g2, wave, 0, &pk);
         if ((tid & 63) == 0) { pv[wave] = pk.best; pi[wave] = pk.idx; ps[wave] = pk.second; }
         __syncthreads();
         if (tid == 0) {

@@ -305,10 +305,9 @@ __global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, con
                 const int x = bi / g.n1, y = bi - x * g.n1;
                 tg.out_ij[2 * b] = min(max(g.guesses[2 * b] - g.r1 + y, 1), g.fh);       // :60-61
                 tg.out_ij[2 * b + 1] = min(max(g.guesses[2 * b + 1] - g.r2 + x, 1), g.fw);
-                exact_flag(g.ex, b, w.best, w.second);
                 range_check(g.ex, g.guesses[2 * b], g.guesses[2 * b + 1], L >> 1, g.fh, g.fw);
                 __hip_atomic_store(&tg.counter[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // with exact mode on, the refinement kernel that follows publishes the ticket (the answer may still change)
+                // (exact mode does not use this variant: dog_finish_kernel combines, refines and publishes there)
                 if (tg.done_flag && b == 0) __hip_atomic_store(tg.done_flag, tg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }

@@ -201,6 +201,7 @@ const Variant kVariants[] = {
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr size_t kMaxLds = 160 * 1024;
 constexpr int kThinMax = 6; // remainder columns done by dog_thin_kernel instead of one more strip
+constexpr int kFinishMaxS = 32; // dog_finish_kernel: at most this many workgroups share one window's refinement
 
 const Variant *find_variant(int id)
 {
@@ -248,11 +249,8 @@ struct pdog_tracker {
     bool exact_all = false;           // pdog_set_exact(t, 2): refine every window with an infinite threshold (tests: the whole reference computation on the device)
     float exact_T = 0.f;              // 2δ
     double *d_K64 = nullptr;          // dir·(g₊⊗g₊ − g₋⊗g₋), l×l column-major, Float64 (:41-43)
-    int *d_ref_count = nullptr;       // [1] refine-list length, [1] finished workgroups
-    int *d_ref_list = nullptr;        // [cap] windows
-    float *d_ref_max = nullptr;       // [cap] their FP32 maxima
     unsigned long long *d_ref_stat = nullptr;
-    double *d_ref_pval = nullptr;     // [cap][nblk] Float64 partial peaks
+    double *d_ref_pval = nullptr;     // [cap][kFinishMaxS] Float64 partial peaks of the finishing kernel's workgroups
     int *d_ref_pidx = nullptr, *d_ref_done = nullptr;
     int ref_cbw = 1, ref_nblk = 1;
     bool ref_tile = false;            // the refinement kernel stages its block's pixels in LDS
@@ -398,20 +396,18 @@ int ensure_capacity(pdog_tracker *t, int n)
     for (int i = 0; i < kNumVariants; ++i)
         if (!kVariants[i].fused) max_strips = std::max(max_strips, (t->n2 + kVariants[i].tw() - 1) / kVariants[i].tw() + kThinMax);
     max_strips = std::max(max_strips, (t->n2 + 7) / 8);
-    for (void *p : {(void *)t->d_part_val, (void *)t->d_part_idx, (void *)t->d_part_sec, (void *)t->d_ref_list, (void *)t->d_ref_max,
-                    (void *)t->d_ref_pval, (void *)t->d_ref_pidx, (void *)t->d_ref_done})
+    for (void *p : {(void *)t->d_part_val, (void *)t->d_part_idx, (void *)t->d_part_sec, (void *)t->d_ref_pval, (void *)t->d_ref_pidx,
+                    (void *)t->d_ref_done})
         if (p) (void)hipFree(p);
     t->d_part_val = t->d_part_sec = nullptr;
     t->d_part_idx = nullptr;
-    t->d_ref_list = nullptr; t->d_ref_max = nullptr; t->d_ref_pval = nullptr; t->d_ref_pidx = nullptr; t->d_ref_done = nullptr;
+    t->d_ref_pval = nullptr; t->d_ref_pidx = nullptr; t->d_ref_done = nullptr;
     t->cap_windows = 0;
     HIP_TRY(hipMalloc(&t->d_part_val, sizeof(float) * (size_t)n * max_strips));
     HIP_TRY(hipMalloc(&t->d_part_sec, sizeof(float) * (size_t)n * max_strips));
     HIP_TRY(hipMalloc(&t->d_part_idx, sizeof(int) * (size_t)n * max_strips));
-    HIP_TRY(hipMalloc(&t->d_ref_list, sizeof(int) * (size_t)n));
-    HIP_TRY(hipMalloc(&t->d_ref_max, sizeof(float) * (size_t)n));
-    HIP_TRY(hipMalloc(&t->d_ref_pval, sizeof(double) * (size_t)n * t->ref_nblk));
-    HIP_TRY(hipMalloc(&t->d_ref_pidx, sizeof(int) * (size_t)n * t->ref_nblk));
+    HIP_TRY(hipMalloc(&t->d_ref_pval, sizeof(double) * (size_t)n * kFinishMaxS));
+    HIP_TRY(hipMalloc(&t->d_ref_pidx, sizeof(int) * (size_t)n * kFinishMaxS));
     HIP_TRY(hipMalloc(&t->d_ref_done, sizeof(int) * (size_t)n));
     HIP_TRY(hipMemset(t->d_ref_done, 0, sizeof(int) * (size_t)n));
     t->cap_windows = n;
@@ -444,41 +440,34 @@ int path_for_batch(const pdog_tracker *t, int n)
 ExactCtl exact_ctl(const pdog_tracker *t)
 {
     ExactCtl x;
-    x.count = t->exact ? t->d_ref_count : nullptr;
-    x.list = t->d_ref_list;
-    x.list_max = t->d_ref_max;
     x.stat = t->d_ref_stat;
     x.range_err = t->d_mail_map ? t->d_mail_map + 5 : nullptr;
     x.T = t->exact_all ? __builtin_huge_valf() : t->exact_T;
     return x;
 }
 
-// The refinement of exact mode (dog_exact.hpp) for the list the kernels of this batch left behind: a persistent grid
-// that exits at once when the list is empty (the usual case).  With done_flag set it also publishes the host
-// functor's ticket once the answer is final.
-constexpr int kRefineGrid = 1024;
-int launch_refine(pdog_tracker *t, const LaunchGeo &g, int32_t *d_out_ij, int32_t *d_done_flag, int32_t done_value)
+// The last kernel of a batch (dog_exact.hpp): strip combine, index map and clamp (:58-61) for every window, and the
+// Float64 refinement of exact mode for the windows that need it.  A large batch gets one workgroup per window (the
+// refinement of the few flagged windows spreads over the GPU by itself); a small one splits each window's column
+// blocks over up to kFinishMaxS workgroups so that a single flagged window does not wait for one CU.
+// With done_flag set the kernel also publishes the host functor's ticket with window 0's final answer.
+int launch_finish(pdog_tracker *t, const LaunchGeo &g, int32_t *d_out_ij, int32_t *d_done_flag, int32_t done_value)
 {
-    if (!t->exact) return PDOG_OK;
-    RefineGeo rg;
-    rg.g = g;
-    rg.count = t->d_ref_count;
-    rg.list = t->d_ref_list;
-    rg.list_max = t->d_ref_max;
-    rg.T = t->exact_all ? __builtin_huge_valf() : t->exact_T;
-    rg.K64 = t->d_K64;
-    rg.cbw = t->ref_cbw;
-    rg.nblk = t->ref_nblk;
-    rg.use_tile = t->ref_tile ? 1 : 0;
-    rg.part_val = t->d_ref_pval;
-    rg.part_idx = t->d_ref_pidx;
-    rg.part_done = t->d_ref_done;
-    rg.out_ij = d_out_ij;
-    rg.blocks_done = t->d_ref_count + 1;
-    rg.done_flag = d_done_flag;
-    rg.done_value = done_value;
-    const int grid = (int)std::min<long long>(kRefineGrid, (long long)g.n * t->ref_nblk);
-    hipLaunchKernelGGL(dog_refine_kernel, dim3(grid), dim3(REFINE_NT), refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_tile), t->stream, rg,
+    FinishGeo fg;
+    fg.g = g;
+    fg.K64 = t->exact ? t->d_K64 : nullptr;
+    fg.cbw = t->ref_cbw;
+    fg.nblk = t->ref_nblk;
+    fg.use_tile = t->ref_tile ? 1 : 0;
+    fg.S = (int)std::max<long long>(1, std::min<long long>(std::min(kFinishMaxS, t->ref_nblk), 2048 / std::max(1, g.n)));
+    fg.part_val = t->d_ref_pval;
+    fg.part_idx = t->d_ref_pidx;
+    fg.part_done = t->d_ref_done;
+    fg.out_ij = d_out_ij;
+    fg.done_flag = d_done_flag;
+    fg.done_value = done_value;
+    const size_t lds = t->exact ? refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_tile) : 0;
+    hipLaunchKernelGGL(dog_finish_kernel, dim3((unsigned)((long long)g.n * fg.S)), dim3(REFINE_NT), lds, t->stream, fg,
                        (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
     HIP_TRY(hipGetLastError());
     return PDOG_OK;
@@ -621,14 +610,29 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         // the auto-detect pass): launches are what such a batch costs, so the DC level is derived inside the row pass
         // and the last column-pass workgroup of a window combines its partials — two launches instead of four.
         constexpr int kLowLatMax = 16; // measured crossover (257×257 and 271×481 windows): 2 launches win up to 16 windows, 4 launches beyond
-        if (n <= kLowLatMax && n <= chunk && hr == 8 && !t->sw.twopass_4l) {
+        // (exact mode: the partials are combined by dog_finish_kernel, which also refines and publishes the ticket —
+        // three launches; without it the last column-pass workgroup of a window combines them itself — two)
+        const bool lowlat = n <= kLowLatMax && n <= chunk && hr == 8 && !t->sw.twopass_4l;
+        if (lowlat && t->exact) {
+            tg.win0 = 0;
+            if (ticket_armed) *ticket_armed = d_done_flag != nullptr;
+            hipLaunchKernelGGL((dog_h1_kernel<13, 8, true>), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
+            HIP_TRY(hipGetLastError());
+            if (d_out_resp)
+                hipLaunchKernelGGL((dog_hpass_kernel<7, 16, true, 8>), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
+            else
+                hipLaunchKernelGGL((dog_hpass_kernel<7, 16, false, 8>), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
+            HIP_TRY(hipGetLastError());
+            return launch_finish(t, g, d_out_ij, d_done_flag, done_value);
+        }
+        if (lowlat) {
             if (!t->d_counter) {
                 HIP_TRY(hipMalloc(&t->d_counter, sizeof(int) * kLowLatMax));
                 HIP_TRY(hipMemsetAsync(t->d_counter, 0, sizeof(int) * kLowLatMax, t->stream));
             }
             tg.counter = t->d_counter;
             tg.win0 = 0;
-            tg.done_flag = t->exact ? nullptr : d_done_flag; // exact mode: the refinement kernel publishes the ticket (the answer is final only then)
+            tg.done_flag = d_done_flag;
             tg.done_value = done_value;
             if (ticket_armed) *ticket_armed = d_done_flag != nullptr;
             hipLaunchKernelGGL((dog_h1_kernel<13, 8, true>), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
@@ -638,7 +642,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
             else
                 hipLaunchKernelGGL((dog_hpass_kernel<7, 16, false, 8, true>), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             HIP_TRY(hipGetLastError());
-            return launch_refine(t, g, d_out_ij, d_done_flag, done_value);
+            return PDOG_OK;
         }
         hipLaunchKernelGGL(dog_dc_kernel, dim3(n), dim3(64), 0, t->stream, g, t->d_dc);
         HIP_TRY(hipGetLastError());
@@ -658,11 +662,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
                 hipLaunchKernelGGL((dog_hpass_kernel<13, 16, false>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             HIP_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL(dog_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, t->stream,
-                           t->d_part_val, t->d_part_idx, t->d_part_sec, g.ex, d_guesses, d_out_ij, n, g.nslots,
-                           t->r1, t->r2, t->n1, FH, FW, t->L >> 1);
-        HIP_TRY(hipGetLastError());
-        return launch_refine(t, g, d_out_ij, nullptr, 0);
+        return launch_finish(t, g, d_out_ij, nullptr, 0);
     }
     const int grid = round_up(g.nblocks, 8);
     if (t->nthin) {
@@ -686,11 +686,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
                        (const f2 *)t->d_taps_row, (const f2 *)(v.roll ? t->d_taps_roll : t->d_taps_col));
     HIP_TRY(hipGetLastError());
     if (t->nthin) HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0)); // join before the strip combine
-    hipLaunchKernelGGL(dog_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, t->stream,
-                       t->d_part_val, t->d_part_idx, t->d_part_sec, g.ex, d_guesses, d_out_ij, n, g.nslots,
-                       t->r1, t->r2, t->n1, FH, FW, t->L >> 1);
-    HIP_TRY(hipGetLastError());
-    return launch_refine(t, g, d_out_ij, nullptr, 0);
+    return launch_finish(t, g, d_out_ij, nullptr, 0);
 }
 
 } // namespace
@@ -872,8 +868,6 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
         CREATE_TRY(hipMemcpy(t->d_K64, K.data(), sizeof(double) * K.size(), hipMemcpyHostToDevice));
         const double delta = std::ldexp(1.0, -24) * (6.0 * t->L + 4.0) * 1.02 + 1e-9;
         t->exact_T = std::nextafter((float)(2.0 * delta), 1.0f);
-        CREATE_TRY(hipMalloc(&t->d_ref_count, sizeof(int) * 2));
-        CREATE_TRY(hipMemset(t->d_ref_count, 0, sizeof(int) * 2));
         CREATE_TRY(hipMalloc(&t->d_ref_stat, sizeof(unsigned long long)));
         CREATE_TRY(hipMemset(t->d_ref_stat, 0, sizeof(unsigned long long)));
         // refinement work items: column blocks whose row-pass result fits ≈20 KB of LDS
@@ -884,7 +878,7 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
         // the block's pixels go to LDS too when they fit beside the row-pass block (l ≲ 120): a candidate's chain then
         // reads LDS instead of waiting for memory once per term
         t->ref_tile = refine_lds_bytes(t->n1, t->L, t->ref_cbw, true) <= 64 * 1024;
-        if (raise_lds_limit((const void *)dog_refine_kernel, refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_tile))) { pdog_destroy(t); return PDOG_E_HIP; }
+        if (raise_lds_limit((const void *)dog_finish_kernel, refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_tile))) { pdog_destroy(t); return PDOG_E_HIP; }
     }
 #undef CREATE_TRY
     rc = ensure_capacity(t, 1);
@@ -901,9 +895,8 @@ int pdog_destroy(pdog_tracker *t)
     if (t->d_taps_row) (void)hipFree(t->d_taps_row);
     if (t->d_taps_col) (void)hipFree(t->d_taps_col);
     if (t->d_taps_roll) (void)hipFree(t->d_taps_roll);
-    for (void *p : {(void *)t->d_part_val, (void *)t->d_part_idx, (void *)t->d_part_sec, (void *)t->d_ref_list, (void *)t->d_ref_max,
-                    (void *)t->d_ref_pval, (void *)t->d_ref_pidx, (void *)t->d_ref_done, (void *)t->d_K64, (void *)t->d_ref_count,
-                    (void *)t->d_ref_stat})
+    for (void *p : {(void *)t->d_part_val, (void *)t->d_part_idx, (void *)t->d_part_sec, (void *)t->d_ref_pval, (void *)t->d_ref_pidx,
+                    (void *)t->d_ref_done, (void *)t->d_K64, (void *)t->d_ref_stat})
         if (p) (void)hipFree(p);
     if (t->d_frame) (void)hipFree(t->d_frame);
     if (t->d_small) (void)hipFree(t->d_small);

@@ -873,9 +873,9 @@ def _tw_for_kernel_len(oracle, l):
     raise AssertionError(l)
 
 
-@pytest.mark.parametrize("l", list(range(17, 98, 4)))
+@pytest.mark.parametrize("l", list(range(17, 106, 4)))
 def test_every_roll_instance_pinned(pt, oracle, l):
-    """One compiled roll-kernel instance per kernel length l = 17, 21, … 97 (dog_roll.hpp).  Small batches are
+    """One compiled roll-kernel instance per kernel length l = 17, 21, … 105 (dog_roll.hpp).  Small batches are
     switched to the fused / two-pass kernels at launch, so the instance is pinned here (pdog_set_variant) and run on
     window shapes that cover a partial strip, an overlapping last strip and remainder columns for the thin kernel —
     positions and the dense response against the oracle, plus the persistent chain kernel of the same instance."""
