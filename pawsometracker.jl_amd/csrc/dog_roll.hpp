@@ -88,8 +88,9 @@ __device__ __forceinline__ void roll_row_pass(f2 (&acc)[ROLL_P], const float *a,
         hi[j] = pair_at(L - U + j); // base of the first hi window: (L-1) - (U-1)
     }
     f2 tn[U];
-#pragma unroll
-    for (int j = 0; j < U; ++j) tn[j] = taps[j];
+    tap_ptr tb = pin_taps(taps); // ONE base re-pinned in place per block: the loads below keep constant offsets from it
+#pragma unroll                   // (an opaque pointer per block made 9 loop-invariant address pairs, all spilled to VGPR lanes)
+    for (int j = 0; j < U; ++j) tn[j] = tb[j];
 #pragma unroll
     for (int k0 = 0; k0 < H; k0 += U) {
         const int nu = (H - k0 < U) ? (H - k0) : U; // the last block is partial when H is not a multiple of U
@@ -98,7 +99,8 @@ __device__ __forceinline__ void roll_row_pass(f2 (&acc)[ROLL_P], const float *a,
 #pragma unroll
         for (int j = 0; j < U; ++j) t[j] = tn[j];
         f2 nlo[U], nhi[U];
-        const tap_ptr tnext = pin_taps(taps + (more ? k0 + U : H));
+        tb = pin_taps(tb);
+        const tap_ptr tnext = tb + (more ? k0 + U : H);
         if (more) {
 #pragma unroll
             for (int j = 0; j < U; ++j) {
@@ -163,15 +165,17 @@ __device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], con
     constexpr int S = roll_slots(L), CH = ROLL_CH, QB = ROLL_QB, NQB = roll_col_blocks(L);
     static_assert(S % 2 == 0 && (CH * SC) % 2 == 0, "pairing needs even slot counts");
     f2 tn[4 * QB];
+    tap_ptr tb = pin_taps(table);
 #pragma unroll
-    for (int j = 0; j < 4 * QB; ++j) tn[j] = table[j];
+    for (int j = 0; j < 4 * QB; ++j) tn[j] = tb[j];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
         f2 t[4 * QB];
 #pragma unroll
         for (int j = 0; j < 4 * QB; ++j) t[j] = tn[j];
         if (qb + 1 < NQB) {
-            const tap_ptr tnext = pin_taps(table + (qb + 1) * 4 * QB);
+            tb = pin_taps(tb);
+            const tap_ptr tnext = tb + (qb + 1) * 4 * QB;
 #pragma unroll
             for (int j = 0; j < 4 * QB; ++j) tn[j] = tnext[j];
         }
@@ -187,7 +191,13 @@ __device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], con
                     if (tt - 1 <= L - 1) {
                         const int slot = ((amod - tt) % S + S) % S; // even
                         const float r = c ? rv[i].y : rv[i].x;
-                        acc2[slot / 2] = fma_bcast(r, t[(par * 2 + c) * QB + m], acc2[slot / 2]);
+                        // An even row's pair (T[0], T[−1] = 0) is the FIRST term of outputs (a, a+1) — the slots the
+                        // sub-chunk S rows earlier emitted: a multiply starts them from scratch (no reset instructions;
+                        // output a+1 starts at ±0 and meets its own first term, row a+1's T[0], later in this block).
+                        if (tt == 0 && c == 0)
+                            acc2[slot / 2] = f2{r, r} * t[(par * 2 + c) * QB + m];
+                        else
+                            acc2[slot / 2] = fma_bcast(r, t[(par * 2 + c) * QB + m], acc2[slot / 2]);
                     }
                 }
             }
@@ -294,12 +304,14 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
         // ---- stage this sub-chunk from the prefetched registers, request the next ----
         if (!(ABL & 4)) {
             float *dst = A + srow * PA + SB * sseg;
-            const float fdc = (float)dc;
+            const f2 ndc = f2{-(float)dc, -(float)dc};
 #pragma unroll
-            for (int i = 0; i < SB; ++i) {
+            for (int i = 0; i < SB; i += 2) { // two pixels per v_pk_add_f32 (v_cvt_f32_ubyteN each): exact integers either way
                 const uint32_t word = pre[i >> 2];
-                const float v = (float)((word >> (8 * (i & 3))) & 0xffu); // v_cvt_f32_ubyteN
-                dst[i] = v - fdc;
+                f2 v = f2{(float)((word >> (8 * (i & 3))) & 0xffu), (float)((word >> (8 * ((i + 1) & 3))) & 0xffu)};
+                v = v + ndc;
+                dst[i] = v.x;
+                dst[i + 1] = v.y;
             }
             if (!(ABL & 8)) load16((sc + 1) * CH + srow, pre);
         }
@@ -349,12 +361,7 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
                     }
                 }
             }
-            // the emitted slots start their next output from zero (they are reused S rows later)
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int slot = ((CH * SC + i - (L - 1)) % S + S) % S;
-                if (slot & 1) acc2[slot / 2].y = 0.f; else acc2[slot / 2].x = 0.f;
-            }
+            // (no reset: the emitted slots are reused S rows later, and their first term is a multiply, see roll_col_body)
         };
         static_assert(NBODY <= 16, "extend the phase switch");
         switch (phase) {
