@@ -102,32 +102,75 @@ __device__ __forceinline__ void peak64_wave_reduce(Peak64 &p)
     }
 }
 
-// ---- refinement of window columns [x0, x0 + ncol) by one workgroup of NT threads (a multiple of 64) ----
-// A deliberately plain separable FP32 evaluation (any evaluation within δ serves: see the header), then the
-// reference's arithmetic for the candidates.  Rlds: NA·ncol f2; tile: NULL, or NA rows of refine_tile_pitch(ncol, L)
-// bytes — the block's pixels with the PaddedView fill materialised, which both passes then read instead of the
-// frame (a candidate's 4225-term chain must not wait for memory 4225 times); lut: 256 doubles; ired/dred: NT/64
-// entries each.  Returns the block's Float64 peak in thread 0 (best = −inf if the block holds no candidate).
+// ---- refinement of one window by one workgroup ----
+// Three stages, each cheaper to reach than the next is to run:
+//   1. FP32 rescan of the column blocks that can hold a pixel within T = 2δ of the window's FP32 maximum M (the main
+//      kernels' per-strip / per-block partial maxima say which: a block whose partial maximum is below M − T cannot):
+//      a deliberately plain separable evaluation (any evaluation within δ serves, see the header) → the CANDIDATES.
+//   2. Every candidate is evaluated in SEPARABLE Float64 (row sums of both Gaussians in double for the block's
+//      columns, then 2l FMAs per candidate): no ordering constraint, so it parallelises, and its error against the
+//      exact value — like the reference's own (l² sequential roundings) — is below δ64 = 2⁻⁵³·(2.1 l² + 8 l + 64).
+//      A candidate more than T64 = 2δ64 below the best of these values cannot be the reference's maximum.
+//   3. The SURVIVORS — one, unless the data holds a genuine near-tie — are evaluated exactly as the reference does it
+//      (exact_pixel: dense l×l, sequential, kernel column-major order); a single survivor needs no evaluation at all.
+// More candidates than the list holds (plateaus: every response exactly equal) → stage 2 is skipped and every
+// candidate goes through stage 3 as it is found (right, only slow).
+constexpr int REFINE_CAP = 512; // candidate list entries
 __host__ __device__ constexpr int refine_tile_pitch(int ncol, int L) { return (ncol + L - 1 + 3) / 4 * 4; }
-__device__ __forceinline__ Peak64 refine_columns(const int NT, const LaunchGeo &g, const uint8_t *__restrict__ frame, int g1, int g2, int x0, int ncol,
-                                                 float thr, tap_ptr trow, tap_ptr tcol, k64_ptr K, f2 *Rlds, uint8_t *tile, double *lut, int *ired,
-                                                 double *dred, bool fill_lut = true)
+// dynamic LDS of a refinement: fixed part (table p/255.0, candidate list, reductions), row-pass block (f2 for stage 1,
+// reused as 2 doubles per element for stage 2), optional pixel tile
+__host__ __device__ constexpr size_t refine_fixed_bytes() { return 256 * 8 + REFINE_CAP * 12 + 16 * 8 + 16 * 4 + 64; }
+__host__ __device__ constexpr size_t refine_r_bytes(int n1, int L, int cbw) { return (size_t)(n1 + L - 1) * cbw * 16; }
+__host__ __device__ constexpr size_t refine_tile_bytes(int n1, int L, int cbw) { return ((size_t)(n1 + L - 1) * refine_tile_pitch(cbw, L) + 15) / 16 * 16; }
+__host__ __device__ constexpr size_t refine_lds_bytes(int n1, int L, int cbw, bool tile = false)
+{
+    return refine_fixed_bytes() + refine_r_bytes(n1, L, cbw) + (tile ? refine_tile_bytes(n1, L, cbw) : 0);
+}
+
+// bits [a, b) of a 64-column strip's lane mask (clipped to the strip)
+__device__ __forceinline__ unsigned long long column_bits(int a, int b)
+{
+    a = max(a, 0);
+    b = min(b, 64);
+    if (b <= a) return 0ull;
+    const unsigned long long hi = b >= 64 ? ~0ull : ((1ull << b) - 1ull);
+    return hi & ~((1ull << a) - 1ull);
+}
+
+struct RefineCtx {
+    tap_ptr trow, tcol;  // FP32 taps: (g₊, g₋)[k] and (s·g₊, −s·g₋)[k]
+    k64_ptr K;           // dense Float64 kernel, l×l column-major (:41-43)
+    k64_ptr g64;         // [2][l]: the normalised Gaussians σ and √2σ in Float64
+    double dir;          // direction, :42
+    double T64;          // 2δ64
+    float T;             // 2δ
+    int cbw, use_tile;
+    unsigned char *lds;  // refine_lds_bytes(n1, l, cbw, use_tile) bytes, 16-aligned
+};
+
+// `may(x0, x1)`: wave-uniform, false only if no pixel of window columns [x0, x1) can reach M − T.
+// Returns the window's answer (column-major index) in thread 0.
+template <typename May>
+__device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, const uint8_t *__restrict__ frame, int g1, int g2, float M,
+                                             const RefineCtx &c, May may)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = NT / 64;
     const int L = g.L, hw = L >> 1, NA = g.n1 + L - 1;
     const int ti0 = g1 - g.r1 - 1 - hw, wj0 = g2 - g.r2 - 1 - hw;
-    const int tp = refine_tile_pitch(ncol, L), tw = ncol + L - 1;
-    if (fill_lut)
-        for (int p = tid; p < 256; p += NT) lut[p] = (double)p / 255.0;
-    if (tile) {
-        for (int e = tid; e < NA * tw; e += NT) {
-            const int a = e / tw, c = e - a * tw;
-            const int gi = ti0 + a, gj = wj0 + x0 + c;
-            int px = g.fill;
-            if (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) px = frame[(long long)gi * g.row_stride + gj];
-            tile[a * tp + c] = (uint8_t)px;
-        }
-    }
+    const float thr = M - c.T;
+    double *lut = reinterpret_cast<double *>(c.lds);
+    double *cand_val = lut + 256;
+    double *dred = cand_val + REFINE_CAP;
+    int *cand_lin = reinterpret_cast<int *>(dred + 16);
+    int *ired = cand_lin + REFINE_CAP;
+    int *cnt = ired + 16; // [0] candidates found, [1] list overflowed, [2] survivors, [3] answer
+    unsigned char *rbase = c.lds + refine_fixed_bytes();
+    f2 *R32 = reinterpret_cast<f2 *>(rbase);
+    double *R64 = reinterpret_cast<double *>(rbase);
+    uint8_t *tile = c.use_tile ? rbase + refine_r_bytes(g.n1, L, c.cbw) : nullptr;
+
+    for (int p = tid; p < 256; p += NT) lut[p] = (double)p / 255.0;
+    if (tid < 4) cnt[tid] = 0;
     // DC level: the same fixed sample grid as the main kernels (any level in 0…255 keeps the bound)
     int sum = dc_sample_sum(g, frame, ti0, wj0, L, tid, NT);
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
@@ -135,114 +178,194 @@ __device__ __forceinline__ Peak64 refine_columns(const int NT, const LaunchGeo &
     __syncthreads();
     int tot = 0;
     for (int w = 0; w < NW; ++w) tot += ired[w];
-    __syncthreads();
     const int dc = dc_from_sum(tot, g.fill);
-    // row pass: R±[a][x] = Σ_k ĝ±[k]·(pixel[a][x0+x+k] − dc), k ascending
-    for (int e = tid; e < NA * ncol; e += NT) {
-        const int a = e / ncol, x = e - a * ncol;
-        f2 acc = f2{0.f, 0.f};
-        if (tile) {
-            const uint8_t *src = tile + a * tp + x;
-            for (int k = 0; k < L; ++k) acc = fma_bcast((float)((int)src[k] - dc), trow[k], acc);
+    __syncthreads();
+
+    // direct = false: stages 1 + 2 (candidates → list with separable Float64 values); direct = true: every candidate
+    // straight to stage 3 (list overflow).  Returns the direct mode's running peak of this thread.
+    auto sweep = [&](bool direct) {
+        Peak64 pk;
+        pk.best = -__builtin_huge_val();
+        pk.idx = 0x7fffffff;
+        for (int x0 = 0; x0 < g.n2; x0 += c.cbw) {
+            const int ncol = min(c.cbw, g.n2 - x0);
+            if (!may(x0, x0 + ncol)) continue;
+            const int tp = refine_tile_pitch(ncol, L), tw = ncol + L - 1;
+            if (tile) {
+                for (int e = tid; e < NA * tw; e += NT) {
+                    const int a = e / tw, cc = e - a * tw;
+                    const int gi = ti0 + a, gj = wj0 + x0 + cc;
+                    int px = g.fill; // PaddedView, :48
+                    if (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) px = frame[(long long)gi * g.row_stride + gj];
+                    tile[a * tp + cc] = (uint8_t)px;
+                }
+                __syncthreads();
+            }
+            auto pixel = [&](int a, int cc) -> int { // tile row a, block column cc (0 … ncol+l−2)
+                if (tile) return tile[a * tp + cc];
+                const int gi = ti0 + a, gj = wj0 + x0 + cc;
+                return (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) ? frame[(long long)gi * g.row_stride + gj] : g.fill;
+            };
+            // stage 1, row pass: R±[a][x] = Σ_k ĝ±[k]·(pixel − dc), k ascending
+            for (int e = tid; e < NA * ncol; e += NT) {
+                const int a = e / ncol, x = e - a * ncol;
+                f2 acc = f2{0.f, 0.f};
+                for (int k = 0; k < L; ++k) acc = fma_bcast((float)(pixel(a, x + k) - dc), c.trow[k], acc);
+                R32[e] = acc;
+            }
+            __syncthreads();
+            const int first = min(cnt[0], REFINE_CAP);
+            __syncthreads();
+            // stage 1, column pass: the candidates
+            for (int e = tid; e < g.n1 * ncol; e += NT) {
+                const int x = e / g.n1, y = e - x * g.n1;
+                float acc = 0.f;
+                for (int t = 0; t < L; ++t) {
+                    const f2 r = R32[(y + t) * ncol + x];
+                    const f2 w = c.tcol[t];
+                    acc = __builtin_fmaf(r.x, w.x, acc);
+                    acc = __builtin_fmaf(r.y, w.y, acc);
+                }
+                if (acc >= thr) {
+                    const int lin = (x0 + x) * g.n1 + y;
+                    if (direct) {
+                        const double F = tile ? exact_patch((const uint8_t *)(tile + y * tp + x), (long long)tp, L, c.K, lut)
+                                              : exact_pixel(frame, g.row_stride, g.fh, g.fw, g.fill, ti0 + y, wj0 + x0 + x, L, c.K, lut);
+                        peak64_push(pk, F, lin);
+                    } else {
+                        const int k = atomicAdd(&cnt[0], 1);
+                        if (k < REFINE_CAP) cand_lin[k] = lin; else cnt[1] = 1;
+                    }
+                }
+            }
+            __syncthreads();
+            const int last = min(cnt[0], REFINE_CAP);
+            if (!direct && last > first && !cnt[1]) {
+                // stage 2: both Gaussians' row sums in Float64 for this block's columns (R32 is dead: same memory) …
+                for (int e = tid; e < NA * ncol; e += NT) {
+                    const int a = e / ncol, x = e - a * ncol;
+                    double sp = 0.0, sm = 0.0;
+                    for (int k = 0; k < L; ++k) {
+                        const double v = lut[pixel(a, x + k)];
+                        sp = __builtin_fma(c.g64[k], v, sp);
+                        sm = __builtin_fma(c.g64[L + k], v, sm);
+                    }
+                    R64[2 * e] = sp;
+                    R64[2 * e + 1] = sm;
+                }
+                __syncthreads();
+                // … and the new candidates' values dir·(Σ g₊[t]·R₊[y+t] − Σ g₋[t]·R₋[y+t])
+                for (int k = first + tid; k < last; k += NT) {
+                    const int lin = cand_lin[k];
+                    const int xw = lin / g.n1, y = lin - xw * g.n1, x = xw - x0;
+                    double sp = 0.0, sm = 0.0;
+                    for (int t = 0; t < L; ++t) {
+                        sp = __builtin_fma(c.g64[t], R64[2 * ((y + t) * ncol + x)], sp);
+                        sm = __builtin_fma(c.g64[L + t], R64[2 * ((y + t) * ncol + x) + 1], sm);
+                    }
+                    cand_val[k] = c.dir * (sp - sm);
+                }
+            }
+            __syncthreads();
+        }
+        return pk;
+    };
+
+    Peak64 pk = sweep(false);
+    const bool overflow = cnt[1] != 0;
+    if (overflow) {
+        __syncthreads();
+        pk = sweep(true);
+    } else {
+        // stage 2 verdict: best separable value; survivors within T64 of it
+        const int n = cnt[0];
+        double m2 = -__builtin_huge_val();
+        for (int k = tid; k < n; k += NT) m2 = fmax(m2, cand_val[k]);
+        for (int off = 32; off > 0; off >>= 1) m2 = fmax(m2, __shfl_xor(m2, off, 64));
+        if (lane == 0) dred[wave] = m2;
+        __syncthreads();
+        for (int w = 0; w < NW; ++w) m2 = fmax(m2, dred[w]);
+        __syncthreads();
+        const double keep = m2 - c.T64;
+        // compact the survivors to the front of the list (order is irrelevant: ties are settled by index)
+        for (int k0 = 0; k0 < n; k0 += NT) {
+            const int k = k0 + tid;
+            const bool s = k < n && cand_val[k] >= keep;
+            const int lin = s ? cand_lin[k] : 0;
+            __syncthreads();
+            if (s) cand_lin[atomicAdd(&cnt[2], 1)] = lin; // lands below k0 + NT: every entry there has been read already
+            __syncthreads();
+        }
+        const int ns = cnt[2];
+        if (ns == 1) {
+            if (tid == 0) cnt[3] = cand_lin[0];
         } else {
-            const int gi = ti0 + a, gj0 = wj0 + x0 + x;
-            const bool rowok = gi >= 0 && gi < g.fh;
-            const uint8_t *src = frame + (long long)gi * g.row_stride;
-            for (int k = 0; k < L; ++k) {
-                const int gj = gj0 + k;
-                int px = g.fill;
-                if (rowok && gj >= 0 && gj < g.fw) px = src[gj];
-                acc = fma_bcast((float)(px - dc), trow[k], acc);
+            for (int k = tid; k < ns; k += NT) {
+                const int lin = cand_lin[k];
+                const int xw = lin / g.n1, y = lin - xw * g.n1;
+                peak64_push(pk, exact_pixel(frame, g.row_stride, g.fh, g.fw, g.fill, ti0 + y, wj0 + xw, L, c.K, lut), lin);
             }
         }
-        Rlds[e] = acc;
-    }
-    __syncthreads();
-    // column pass + candidates
-    Peak64 pk;
-    pk.best = -__builtin_huge_val();
-    pk.idx = 0x7fffffff;
-    for (int e = tid; e < g.n1 * ncol; e += NT) {
-        const int x = e / g.n1, y = e - x * g.n1;
-        float acc = 0.f;
-        for (int t = 0; t < L; ++t) {
-            const f2 r = Rlds[(y + t) * ncol + x];
-            const f2 w = tcol[t];
-            acc = __builtin_fmaf(r.x, w.x, acc);
-            acc = __builtin_fmaf(r.y, w.y, acc);
-        }
-        if (acc >= thr) {
-            const double F = tile ? exact_patch((const uint8_t *)(tile + y * tp + x), (long long)tp, L, K, lut)
-                                  : exact_pixel(frame, g.row_stride, g.fh, g.fw, g.fill, ti0 + y, wj0 + x0 + x, L, K, lut);
-            peak64_push(pk, F, (x0 + x) * g.n1 + y);
-        }
+        if (ns == 1) { __syncthreads(); return cnt[3]; }
     }
     peak64_wave_reduce(pk);
     __syncthreads();
     if (lane == 0) { dred[wave] = pk.best; ired[wave] = pk.idx; }
     __syncthreads();
-    if (tid == 0)
+    if (tid == 0) {
         for (int w = 1; w < NW; ++w) peak64_push(pk, dred[w], ired[w]);
+        cnt[3] = pk.idx;
+    }
     __syncthreads();
-    return pk;
+    return cnt[3];
 }
 
 // ---- the last kernel of a batch: strip combine + index map + clamp (:58-61), and the refinement of exact mode ----
-// S workgroups per window.  Every one of them combines the window's partial peaks (a handful of loads); part 0
-// writes the FP32 answer, checks the guess's range and — the usual case — that is all: the runner-up lies further
-// than 2δ below the maximum.  Otherwise the S workgroups share the window's column blocks, re-evaluate the
-// near-maximal pixels in the reference's arithmetic, and the last one to finish writes the reference's answer.
+// One workgroup per window.  Thread 0 combines the window's partial peaks (a handful of loads), writes the FP32 answer,
+// checks the guess's range and — the usual case — that is all: the runner-up lies further than 2δ below the maximum.
+// Otherwise the workgroup refines the window (above) and writes the reference's answer.
 struct FinishGeo {
     LaunchGeo g;                 // frames, strides, frame_index, guesses, geometry, part_val/idx/sec, nslots, ex
     const double *K64;           // l×l, column-major, dir·(g₊⊗g₊ − g₋⊗g₋) (:41-43); null = exact mode off
-    int cbw, nblk;               // window columns per column block; column blocks per window
-    int use_tile;                // the block's pixels are staged in LDS behind the row-pass block
-    int S;                       // workgroups per window
-    double *part_val;            // [n][S] Float64 partial peaks
-    int *part_idx;               // [n][S]
-    int *part_done;              // [n] zero between launches
+    const double *g64;           // [2][l] Float64 Gaussians
+    double dir, T64;
+    int cbw, use_tile;
+    // how the partial slots map to window columns: slot s < nmain covers [min(s·slot_w, slot_last) … + slot_w) (the
+    // roll kernel shifts its last strip left: slot_last = covered − slot_w; others: slot_last = huge), slots ≥ nmain
+    // are single columns thin_x0 + (s − nmain)
+    int slot_w, slot_last, nmain, thin_x0;
+    int use_mask;                // the main slots carry per-column masks (roll kernel, slot_w = 64)
     int32_t *out_ij;             // [n][2]
     int32_t *done_flag;          // NULL or host-coherent ticket word (see dog_fused.hpp): published with window 0's final answer
     int32_t done_value;
 };
 
 constexpr int REFINE_NT = 256;
-__host__ __device__ constexpr size_t refine_r_bytes(int n1, int L, int cbw) { return ((size_t)(n1 + L - 1) * cbw * sizeof(f2) + 15) / 16 * 16; }
-__host__ __device__ constexpr size_t refine_tile_bytes(int n1, int L, int cbw) { return (size_t)(n1 + L - 1) * refine_tile_pitch(cbw, L); }
-__host__ __device__ constexpr size_t refine_lds_bytes(int n1, int L, int cbw, bool tile = false)
-{
-    return refine_r_bytes(n1, L, cbw) + (tile ? refine_tile_bytes(n1, L, cbw) : 0);
-}
 
 static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const FinishGeo fg, const f2 *__restrict__ taps_row,
                                                                       const f2 *__restrict__ taps_col)
 {
-    constexpr int NT = REFINE_NT, NW = NT / 64;
+    constexpr int NT = REFINE_NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ double lut[256];
-    __shared__ double dred[NW];
-    __shared__ int ired[NW];
-    __shared__ int s_refine, s_last;
+    __shared__ int s_refine;
     __shared__ float s_max;
     const LaunchGeo &g = fg.g;
     const int tid = threadIdx.x;
-    const int b = blockIdx.x / fg.S, part = blockIdx.x - b * fg.S;
+    const int b = blockIdx.x;
     const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
     if (tid == 0) {
         Peak pk;
         peak_init(pk);
         for (int s = 0; s < g.nslots; ++s) peak_merge(pk, g.part_val[b * g.nslots + s], g.part_idx[b * g.nslots + s], g.part_sec[b * g.nslots + s]);
         const bool rf = fg.K64 && (pk.best - pk.second <= g.ex.T);
-        if (part == 0) {
-            range_check(g.ex, g1, g2, g.L >> 1, g.fh, g.fw);
-            if (rf) {
-                atomicAdd(g.ex.stat, 1ull);
-            } else {
-                const int x = pk.idx / g.n1, y = pk.idx - x * g.n1;
-                fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);       // :60-61
-                fg.out_ij[2 * b + 1] = min(max(g2 - g.r2 + x, 1), g.fw);
-                if (fg.done_flag && b == 0) __hip_atomic_store(fg.done_flag, fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+        range_check(g.ex, g1, g2, g.L >> 1, g.fh, g.fw);
+        if (rf) {
+            atomicAdd(g.ex.stat, 1ull);
+        } else {
+            const int x = pk.idx / g.n1, y = pk.idx - x * g.n1;
+            fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);       // :60-61
+            fg.out_ij[2 * b + 1] = min(max(g2 - g.r2 + x, 1), g.fw);
+            if (fg.done_flag && b == 0) __hip_atomic_store(fg.done_flag, fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         s_refine = rf;
         s_max = pk.best;
@@ -251,36 +374,38 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
     if (!s_refine) return;
     const int fidx = g.frame_index ? g.frame_index[b] : b;
     const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
+    RefineCtx c;
+    c.trow = as_taps(taps_row);
+    c.tcol = as_taps(taps_col);
+    c.K = (k64_ptr)(unsigned long long)fg.K64;
+    c.g64 = (k64_ptr)(unsigned long long)fg.g64;
+    c.dir = fg.dir;
+    c.T64 = fg.T64;
+    c.T = g.ex.T;
+    c.cbw = fg.cbw;
+    c.use_tile = fg.use_tile;
+    c.lds = smem;
     const float thr = s_max - g.ex.T;
-    Peak64 mine;
-    mine.best = -__builtin_huge_val();
-    mine.idx = 0x7fffffff;
-    for (int cb = part; cb < fg.nblk; cb += fg.S) {
-        const int x0 = cb * fg.cbw, ncol = min(fg.cbw, g.n2 - x0);
-        const Peak64 pk = refine_columns(NT, g, frame, g1, g2, x0, ncol, thr, as_taps(taps_row), as_taps(taps_col), (k64_ptr)(unsigned long long)fg.K64,
-                                         reinterpret_cast<f2 *>(smem), fg.use_tile ? smem + refine_r_bytes(g.n1, g.L, fg.cbw) : nullptr, lut, ired, dred);
-        if (tid == 0) peak64_push(mine, pk.best, pk.idx);
-    }
+    const float *pv = g.part_val + (long long)b * g.nslots;
+    const unsigned long long *pm = g.part_mask + (long long)b * g.nslots;
+    auto may = [&](int x0, int x1) {
+        bool any = false;
+        for (int s = 0; s < g.nslots; ++s) { // a handful of slots; uniform
+            int lo, hi;
+            if (s < fg.nmain) { lo = min(s * fg.slot_w, fg.slot_last); hi = lo + fg.slot_w; }
+            else { lo = fg.thin_x0 + (s - fg.nmain); hi = lo + 1; }
+            if (lo < x1 && hi > x0 && pv[s] >= thr && (!fg.use_mask || s >= fg.nmain || (pm[s] & column_bits(x0 - lo, x1 - lo)))) any = true;
+        }
+        return any;
+    };
+    const int idx = refine_window(NT, g, frame, g1, g2, s_max, c, may);
     if (tid == 0) {
-        __hip_atomic_store(&fg.part_val[(long long)b * fg.S + part], mine.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&fg.part_idx[(long long)b * fg.S + part], mine.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int old = __hip_atomic_fetch_add(&fg.part_done[b], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (old == fg.S - 1);
-        if (s_last) { // this window's last workgroup: first Float64 maximum over all of them → position (:59-61)
-            Peak64 w;
-            w.best = -__builtin_huge_val();
-            w.idx = 0x7fffffff;
-            for (int k = 0; k < fg.S; ++k)
-                peak64_push(w, __hip_atomic_load(&fg.part_val[(long long)b * fg.S + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                            __hip_atomic_load(&fg.part_idx[(long long)b * fg.S + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            const int x = w.idx / g.n1, y = w.idx - x * g.n1;
-            fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);
-            fg.out_ij[2 * b + 1] = min(max(g2 - g.r2 + x, 1), g.fw);
-            __hip_atomic_store(&fg.part_done[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (fg.done_flag && b == 0) {
-                __threadfence_system();
-                __hip_atomic_store(fg.done_flag, fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+        const int x = idx / g.n1, y = idx - x * g.n1;
+        fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);
+        fg.out_ij[2 * b + 1] = min(max(g2 - g.r2 + x, 1), g.fw);
+        if (fg.done_flag && b == 0) {
+            __threadfence_system();
+            __hip_atomic_store(fg.done_flag, fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

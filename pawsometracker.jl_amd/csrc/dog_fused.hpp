@@ -34,6 +34,9 @@ struct FusedGeo {
     int32_t done_value;  // window 0's answer is written: the host functor polls it instead of waiting for the kernel's end
     int progress;        // != 0: done_flag receives k + 1 after every frame k of clip 0 instead (a host consumer follows the chain)
     const double *K64;   // the reference's dense Float64 kernel, l×l column-major (exact mode, dog_exact.hpp); null = off
+    const double *g64;   // [2][l] Float64 Gaussians (the refinement's separable stage)
+    double dir, T64;
+    int ref_cbw, ref_tile; // the refinement's column-block width / LDS pixel tile (its scratch is this kernel's dynamic LDS)
 };
 
 constexpr int FUSED_NT = 1024, FUSED_PMAX = 8, FUSED_U = 8;
@@ -141,19 +144,21 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
     __shared__ int s_idx[NW];
     __shared__ int s_guess[2];
     __shared__ float s_sec[NW];
-    __shared__ double s_lut[256], s_dred[NW]; // exact mode: p / 255.0 and the wave peaks of the Float64 re-evaluation
     __shared__ int s_refine;
     __shared__ float s_max;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const tap_ptr trow = as_taps(taps_row), tcol = as_taps(taps_col);
-    if (fg.K64 && tid < 256) s_lut[tid] = (double)tid / 255.0;
 
     // tile columns c ≥ TWin and RT columns a ≥ NA are only ever read by the sliding windows of masked outputs: zero once
-    for (int r = wave; r < NA; r += NW)
-        for (int c = fg.TWin + lane; c < fg.pitchA; c += 64) A[r * fg.pitchA + c] = 0.f;
-    for (int x = wave; x < g.n2; x += NW)
-        for (int c = NA + lane; c < fg.pitchV; c += 64) Vs[x * fg.pitchV + c] = f2{0.f, 0.f};
+    // (and again after a refinement, which uses this LDS as its scratch)
+    auto zero_padding = [&]() {
+        for (int r = wave; r < NA; r += NW)
+            for (int c = fg.TWin + lane; c < fg.pitchA; c += 64) A[r * fg.pitchA + c] = 0.f;
+        for (int x = wave; x < g.n2; x += NW)
+            for (int c = NA + lane; c < fg.pitchV; c += 64) Vs[x * fg.pitchV + c] = f2{0.f, 0.f};
+    };
+    zero_padding();
 
     int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
     for (int k = 0; k < fg.chain_len; ++k) {
@@ -308,44 +313,22 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
         }
         __syncthreads();
         if (s_refine) {
-            // RT is still in LDS: one more sweep of the column pass finds the pixels within 2δ of the maximum; each is
-            // re-evaluated as the reference does it (dense l×l Float64 in kernel column-major order, :57) from the LDS
-            // tile — A holds (float)(pixel − dc), exact integers — and the first maximum of THOSE values wins (:59).
-            const float thr = s_max - g.ex.T;
-            const k64_ptr K = (k64_ptr)(unsigned long long)fg.K64;
-            const int dc = dc_from_sum([&] { int t = 0; for (int w = 0; w < NW; ++w) t += s_sum[w]; return t; }(), g.fill);
-            Peak64 p64;
-            p64.best = -__builtin_huge_val();
-            p64.idx = 0x7fffffff;
-            for (int e = tid; e < g.n1 * g.n2; e += NT) {
-                const int x = e / g.n1, y = e - x * g.n1;
-                const f2 *a = Vs + x * fg.pitchV + y;
-                f2 acc = f2{0.f, 0.f};
-                for (int t = 0; t < L; ++t) acc = fma_pair(a[t], tcol[t], acc);
-                if (acc.x + acc.y >= thr) {
-                    double tmp = 0.0;
-                    for (int kj = 0; kj < L; ++kj) {
-                        const float *col = A + y * fg.pitchA + x + kj;
-                        const k64_ptr kc = K + (long long)L * kj;
-                        int ki = 0;
-                        for (; ki + 8 <= L; ki += 8) { // the 8 tile and table reads go out together; only the additions are a chain
-                            double a8[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) a8[u] = s_lut[(int)col[(ki + u) * fg.pitchA] + dc];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) tmp = exact_mac(tmp, a8[u], kc[ki + u]);
-                        }
-                        for (; ki < L; ++ki) tmp = exact_mac(tmp, s_lut[(int)col[ki * fg.pitchA] + dc], kc[ki]);
-                    }
-                    peak64_push(p64, tmp, e);
-                }
-            }
-            peak64_wave_reduce(p64);
-            if (lane == 0) { s_dred[wave] = p64.best; s_idx[wave] = p64.idx; }
-            __syncthreads();
+            // A near-tie: the reference's own arithmetic decides (dog_exact.hpp: FP32 rescan → separable Float64 →
+            // sequential dense chains for genuine ties).  The tile and RT are not needed any more: their LDS is the scratch.
+            RefineCtx c;
+            c.trow = trow;
+            c.tcol = tcol;
+            c.K = (k64_ptr)(unsigned long long)fg.K64;
+            c.g64 = (k64_ptr)(unsigned long long)fg.g64;
+            c.dir = fg.dir;
+            c.T64 = fg.T64;
+            c.T = g.ex.T;
+            c.cbw = fg.ref_cbw;
+            c.use_tile = fg.ref_tile;
+            c.lds = smem;
+            const int idx = refine_window(NT, g, frame, g1, g2, s_max, c, [](int, int) { return true; });
             if (tid == 0) {
-                for (int w = 1; w < NW; ++w) peak64_push(p64, s_dred[w], s_idx[w]);
-                const int x = p64.idx / g.n1, y = p64.idx - x * g.n1;
+                const int x = idx / g.n1, y = idx - x * g.n1;
                 const int i = min(max(g1 - g.r1 + y, 1), g.fh);
                 const int j = min(max(g2 - g.r2 + x, 1), g.fw);
                 o_ij[0] = i;
@@ -356,6 +339,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
                     __hip_atomic_store(fg.done_flag, fg.progress ? k + 1 : fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             __syncthreads();
+            if (k + 1 < fg.chain_len) { zero_padding(); }
         }
         stamp(3);
         g1 = s_guess[0];   // :167 — the next frame's guess

@@ -96,6 +96,7 @@ struct LaunchGeo {
     float *__restrict__ part_val;        // n x nslots
     int *__restrict__ part_idx;          // n x nslots
     float *__restrict__ part_sec;        // n x nslots: runner-up value of each partial
+    unsigned long long *__restrict__ part_mask; // n x nslots, roll kernel only: lanes (columns) of the strip whose maximum lies within ex.T of the strip's
     ExactCtl ex;
     int fh, fw, r1, r2, n1, n2, L, fill, nstrips, n;
     int RR, pitchA;                      // only read by runtime-L variants

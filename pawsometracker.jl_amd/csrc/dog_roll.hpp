@@ -159,59 +159,100 @@ __host__ __device__ constexpr int roll_col_table_len(int L) { return roll_col_bl
 // Column pass body for sub-chunk phase SC (rows a ≡ CH*SC + i mod S).  rv[i] = (R+, R−)[row i][x].
 // Loop order (tap block, row, channel): every output receives its terms as t = 0: (+,−), 1: (+,−), …
 // whatever its alignment to blocks and sub-chunks, so equal inputs give bit-equal outputs.
-template <int L, int SC>
-__device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], const f2 (&rv)[ROLL_CH], tap_ptr table)
+// QHI < roll_col_blocks(L): a prologue body.  The first input rows a < l−1 have no output above row 0 to feed: rows
+// a … a+7 of sub-chunk sc only need taps t ≤ a+7, i.e. tap blocks 0 … 2sc+1 — the rest of the scatter would land in
+// slots whose outputs do not exist (20 % of the column pass's FMAs over the first and last l−1 rows).  Up there the
+// phase equals the sub-chunk number, so the shortened bodies are static instances with no branch inside.
+__host__ __device__ constexpr int roll_prologue_blocks(int sc) { return 2 * sc + 2; }
+__host__ __device__ constexpr int roll_prologue_len(int L) { return (roll_col_blocks(L) - 2 + 1) / 2; } // sub-chunks with fewer blocks than the full body
+// One tap block of the column pass: requests the next block's taps, then this block's FMAs for the 8 rows.
+template <int L, int SC, int NQB, int qb>
+__device__ __forceinline__ void roll_col_block(f2 (&acc2)[roll_slots(L) / 2], const f2 (&rv)[ROLL_CH], f2 (&tn)[4 * ROLL_QB], tap_ptr &tb)
 {
-    constexpr int S = roll_slots(L), CH = ROLL_CH, QB = ROLL_QB, NQB = roll_col_blocks(L);
-    static_assert(S % 2 == 0 && (CH * SC) % 2 == 0, "pairing needs even slot counts");
-    f2 tn[4 * QB];
-    tap_ptr tb = pin_taps(table);
+    constexpr int S = roll_slots(L), CH = ROLL_CH, QB = ROLL_QB;
+    f2 t[4 * QB];
 #pragma unroll
-    for (int j = 0; j < 4 * QB; ++j) tn[j] = tb[j];
+    for (int j = 0; j < 4 * QB; ++j) t[j] = tn[j];
+    if (qb + 1 < NQB) {
+        tb = pin_taps(tb);
+        const tap_ptr tnext = tb + (qb + 1) * 4 * QB;
 #pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) {
-        f2 t[4 * QB];
+        for (int j = 0; j < 4 * QB; ++j) tn[j] = tnext[j];
+    }
 #pragma unroll
-        for (int j = 0; j < 4 * QB; ++j) t[j] = tn[j];
-        if (qb + 1 < NQB) {
-            tb = pin_taps(tb);
-            const tap_ptr tnext = tb + (qb + 1) * 4 * QB;
+    for (int i = 0; i < CH; ++i) {
+        const int par = i & 1;
+        const int amod = CH * SC + i;
 #pragma unroll
-            for (int j = 0; j < 4 * QB; ++j) tn[j] = tnext[j];
-        }
+        for (int c = 0; c < 2; ++c) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int par = i & 1;
-            const int amod = CH * SC + i;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-#pragma unroll
-                for (int m = 0; m < QB; ++m) {
-                    const int tt = par + 2 * (QB * qb + m); // taps (tt, tt-1)
-                    if (tt - 1 <= L - 1) {
-                        const int slot = ((amod - tt) % S + S) % S; // even
-                        const float r = c ? rv[i].y : rv[i].x;
-                        // An even row's pair (T[0], T[−1] = 0) is the FIRST term of outputs (a, a+1) — the slots the
-                        // sub-chunk S rows earlier emitted: a multiply starts them from scratch (no reset instructions;
-                        // output a+1 starts at ±0 and meets its own first term, row a+1's T[0], later in this block).
-                        if (tt == 0 && c == 0)
-                            acc2[slot / 2] = f2{r, r} * t[(par * 2 + c) * QB + m];
-                        else
-                            acc2[slot / 2] = fma_bcast(r, t[(par * 2 + c) * QB + m], acc2[slot / 2]);
-                    }
+            for (int m = 0; m < QB; ++m) {
+                const int tt = par + 2 * (QB * qb + m); // taps (tt, tt-1)
+                if (tt - 1 <= L - 1) {
+                    const int slot = ((amod - tt) % S + S) % S; // even
+                    const float r = c ? rv[i].y : rv[i].x;
+                    // An even row's pair (T[0], T[−1] = 0) is the FIRST term of outputs (a, a+1) — the slots the
+                    // sub-chunk S rows earlier emitted: a multiply starts them from scratch (no reset instructions;
+                    // output a+1 starts at ±0 and meets its own first term, row a+1's T[0], later in this block).
+                    if (tt == 0 && c == 0)
+                        acc2[slot / 2] = f2{r, r} * t[(par * 2 + c) * QB + m];
+                    else
+                        acc2[slot / 2] = fma_bcast(r, t[(par * 2 + c) * QB + m], acc2[slot / 2]);
                 }
             }
         }
-        // pin exactly the pairs this block touched (pinning idle ones makes the allocator copy them)
+    }
+    // pin exactly the pairs this block touched (pinning idle ones makes the allocator copy them)
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
+    for (int i = 0; i < CH; ++i) {
 #pragma unroll
-            for (int m = 0; m < QB; ++m) {
-                const int tt = (i & 1) + 2 * (QB * qb + m);
-                if (tt - 1 <= L - 1) pin_acc(acc2[(((CH * SC + i - tt) % S + S) % S) / 2]);
-            }
+        for (int m = 0; m < QB; ++m) {
+            const int tt = (i & 1) + 2 * (QB * qb + m);
+            if (tt - 1 <= L - 1) pin_acc(acc2[(((CH * SC + i - tt) % S + S) % S) / 2]);
         }
-        __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// QHI < roll_col_blocks(L): a PROLOGUE body, blocks 0 … QHI−1 only (see above).  Full bodies (QHI = all blocks) are
+// entered at block `qlo` through a switch that falls through to the end: the last l−1 input rows have no output
+// below row n1−1 to feed, rows a … a+7 only need taps t ≥ a − (n1−1), so the leading blocks are skipped with ONE
+// scalar jump and no branch between blocks (qlo = 0 everywhere else).
+template <int L, int SC, int QHI = roll_col_blocks(L)>
+__device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], const f2 (&rv)[ROLL_CH], tap_ptr table, int qlo)
+{
+    constexpr int S = roll_slots(L), CH = ROLL_CH, QB = ROLL_QB, NQB = QHI;
+    static_assert(QHI >= 1 && QHI <= roll_col_blocks(L), "tap-block bound out of range");
+    static_assert(S % 2 == 0 && (CH * SC) % 2 == 0, "pairing needs even slot counts");
+    static_assert(roll_col_blocks(L) <= 28, "extend the entry switch");
+    f2 tn[4 * QB];
+    tap_ptr tb = pin_taps(table);
+    if constexpr (QHI < roll_col_blocks(L)) {
+#pragma unroll
+        for (int j = 0; j < 4 * QB; ++j) tn[j] = tb[j];
+        auto run = [&](auto self, auto QBc) {
+            constexpr int qb = decltype(QBc)::value;
+            if constexpr (qb < NQB) {
+                roll_col_block<L, SC, NQB, qb>(acc2, rv, tn, tb);
+                self(self, std::integral_constant<int, qb + 1>{});
+            }
+        };
+        run(run, std::integral_constant<int, 0>{});
+    } else {
+        const tap_ptr t0 = tb + qlo * (4 * QB); // the entry block's taps
+#pragma unroll
+        for (int j = 0; j < 4 * QB; ++j) tn[j] = t0[j];
+#define PDOG_BLK(k)                                                                  \
+    case k:                                                                          \
+        if constexpr ((k) < NQB) roll_col_block<L, SC, NQB, ((k) < NQB ? (k) : 0)>(acc2, rv, tn, tb); \
+        [[fallthrough]];
+        switch (qlo) {
+            PDOG_BLK(0) PDOG_BLK(1) PDOG_BLK(2) PDOG_BLK(3) PDOG_BLK(4) PDOG_BLK(5) PDOG_BLK(6) PDOG_BLK(7) PDOG_BLK(8) PDOG_BLK(9)
+            PDOG_BLK(10) PDOG_BLK(11) PDOG_BLK(12) PDOG_BLK(13) PDOG_BLK(14) PDOG_BLK(15) PDOG_BLK(16) PDOG_BLK(17) PDOG_BLK(18)
+            PDOG_BLK(19) PDOG_BLK(20) PDOG_BLK(21) PDOG_BLK(22) PDOG_BLK(23) PDOG_BLK(24) PDOG_BLK(25) PDOG_BLK(26) PDOG_BLK(27)
+        default: break;
+        }
+#undef PDOG_BLK
     }
 }
 
@@ -222,10 +263,11 @@ __device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], con
 template <int LT, bool RESP, int ABL>
 __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restrict__ taps_row, const f2 *__restrict__ taps_col,
                                            unsigned char *smem, const uint8_t *__restrict__ frame, int g1, int g2, int s,
-                                           int b, int logical, Peak &peak_out)
+                                           int b, int logical, Peak &peak_out, unsigned long long &mask_out)
 {
     constexpr int L = LT, hw = L / 2, S = roll_slots(L), CH = ROLL_CH, P = ROLL_P, TW = ROLL_TW;
     constexpr int NBODY = S / CH;
+    constexpr int NPRO = (ABL == 0) ? roll_prologue_len(L) : 0; // sub-chunks at the top that run shortened column-pass bodies
     static_assert(S % CH == 0, "slot count must be a multiple of the sub-chunk");
     static_assert(CH == 8 && L % 4 == 1 && L >= ROLL_LMIN && L <= ROLL_LMAX, "roll kernel instance out of range");
     constexpr int SB = roll_sb(L);     // staged bytes per lane per sub-chunk (16 for l = 65)
@@ -339,9 +381,11 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
 #pragma unroll
         for (int i = 0; i < CH; ++i) rv[i] = Rb[i * ROLL_PR + lane];
         const int phase = sc % NBODY;
-        auto emit = [&](auto SCc) {
-            constexpr int SC = decltype(SCc)::value;
-            if (!(ABL & 1)) roll_col_body<L, SC>(acc2, rv, tcol);
+        // rows a = CH·sc … +7 need taps t ≥ a − (n1−1); block qb holds taps 4qb−1 … 4qb+3: blocks below qlo feed nothing
+        const int qlo = (ABL == 0) ? min(roll_col_blocks(L) - 1, max(0, (sc * CH - g.n1 - 2 + 3) >> 2)) : 0;
+        auto emit = [&](auto SCc, auto QHIc) {
+            constexpr int SC = decltype(SCc)::value, QHI = decltype(QHIc)::value;
+            if (!(ABL & 1)) roll_col_body<L, SC, QHI>(acc2, rv, tcol, qlo);
             // outputs y = a − (l−1) for the 8 rows of this sub-chunk are complete.  A lane owns ONE
             // column and meets its rows in increasing y (= increasing column-major index), so a strict
             // '>' keeps the first maximum of the lane (findmax, :59); ties between lanes and strips
@@ -363,25 +407,27 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
             }
             // (no reset: the emitted slots are reused S rows later, and their first term is a multiply, see roll_col_body)
         };
-        static_assert(NBODY <= 16, "extend the phase switch");
-        switch (phase) {
-        case 0: emit(std::integral_constant<int, 0>{}); break;
-        case 1: emit(std::integral_constant<int, 1 % NBODY>{}); break;
-        case 2: emit(std::integral_constant<int, 2 % NBODY>{}); break;
-        case 3: emit(std::integral_constant<int, 3 % NBODY>{}); break;
-        case 4: emit(std::integral_constant<int, 4 % NBODY>{}); break;
-        case 5: emit(std::integral_constant<int, 5 % NBODY>{}); break;
-        case 6: emit(std::integral_constant<int, 6 % NBODY>{}); break;
-        case 7: emit(std::integral_constant<int, 7 % NBODY>{}); break;
-        case 8: emit(std::integral_constant<int, 8 % NBODY>{}); break;
-        case 9: emit(std::integral_constant<int, 9 % NBODY>{}); break;
-        case 10: emit(std::integral_constant<int, 10 % NBODY>{}); break;
-        case 11: emit(std::integral_constant<int, 11 % NBODY>{}); break;
-        case 12: emit(std::integral_constant<int, 12 % NBODY>{}); break;
-        case 13: emit(std::integral_constant<int, 13 % NBODY>{}); break;
-        case 14: emit(std::integral_constant<int, 14 % NBODY>{}); break;
-        default: emit(std::integral_constant<int, 15 % NBODY>{}); break;
+        static_assert(NBODY <= 16 && NPRO < NBODY && NPRO <= 16, "extend the phase switches");
+#define PDOG_FULL(k) case k: emit(std::integral_constant<int, (k) % NBODY>{}, std::integral_constant<int, roll_col_blocks(L)>{}); break;
+#define PDOG_PRO(k)                                                                                                   \
+    case k:                                                                                                           \
+        if constexpr ((k) < NPRO) emit(std::integral_constant<int, (k) % NBODY>{}, std::integral_constant<int, ((k) < NPRO ? roll_prologue_blocks(k) : 1)>{}); \
+        break;
+        if (sc < NPRO) { // the first rows: shortened bodies (sub-chunk = phase)
+            switch (sc) {
+                PDOG_PRO(0) PDOG_PRO(1) PDOG_PRO(2) PDOG_PRO(3) PDOG_PRO(4) PDOG_PRO(5) PDOG_PRO(6) PDOG_PRO(7)
+                PDOG_PRO(8) PDOG_PRO(9) PDOG_PRO(10) PDOG_PRO(11) PDOG_PRO(12) PDOG_PRO(13) PDOG_PRO(14) PDOG_PRO(15)
+            default: break;
+            }
+        } else {
+            switch (phase) {
+                PDOG_FULL(0) PDOG_FULL(1) PDOG_FULL(2) PDOG_FULL(3) PDOG_FULL(4) PDOG_FULL(5) PDOG_FULL(6) PDOG_FULL(7)
+                PDOG_FULL(8) PDOG_FULL(9) PDOG_FULL(10) PDOG_FULL(11) PDOG_FULL(12) PDOG_FULL(13) PDOG_FULL(14)
+            default: emit(std::integral_constant<int, 15 % NBODY>{}, std::integral_constant<int, roll_col_blocks(L)>{}); break;
+            }
         }
+#undef PDOG_FULL
+#undef PDOG_PRO
         __builtin_amdgcn_wave_barrier(); // A / Rb are rewritten by the next sub-chunk
     }
 
@@ -394,8 +440,13 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
     pk.second = second;
     pk.idx = (x0 + lane) * g.n1 + best_y;
     if (lane >= ws) peak_init(pk);
+    const float colbest = pk.best;
     peak_wave_reduce(pk);
     peak_out = pk;         // valid in lane 0
+    // exact mode: which columns of the strip can hold a pixel within T of the window's maximum (≥ the strip's): the
+    // refinement rescans only those
+    const float sb = __shfl(pk.best, 0, 64);
+    mask_out = __builtin_amdgcn_ballot_w64(colbest >= sb - g.ex.T);
 }
 
 
@@ -413,15 +464,17 @@ __device__ __forceinline__ unsigned long long uniform_u64(const void *p)
 }
 template <int LT>
 __device__ __attribute__((noinline)) void roll_strip_call(const LaunchGeo *gp, const f2 *taps_row, const f2 *taps_col, unsigned char *smem,
-                                                          const uint8_t *frame, int g1, int g2, int s, int b, Peak *out)
+                                                          const uint8_t *frame, int g1, int g2, int s, int b, Peak *out, unsigned long long *mask)
 {
     LaunchGeo g;
     __builtin_memcpy(&g, (const void *)uniform_u64(gp), sizeof g);
     Peak pk;
+    unsigned long long m;
     roll_strip<LT, false, 0>(g, (const f2 *)uniform_u64(taps_row), (const f2 *)uniform_u64(taps_col), smem, (const uint8_t *)uniform_u64(frame),
                              __builtin_amdgcn_readfirstlane(g1), __builtin_amdgcn_readfirstlane(g2), __builtin_amdgcn_readfirstlane(s),
-                             __builtin_amdgcn_readfirstlane(b), 0, pk);
+                             __builtin_amdgcn_readfirstlane(b), 0, pk, m);
     *out = pk;
+    *mask = m;
 }
 constexpr int ROLL_CALL_LMIN = 101; // batch kernels from this length on run the out-of-line strip too
 
@@ -440,11 +493,13 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
     const int fidx = g.frame_index ? g.frame_index[b] : b;
     const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
     Peak pk;
+    unsigned long long mask;
     if constexpr (LT >= ROLL_CALL_LMIN && !RESP && ABL == 0)
-        roll_strip_call<LT>(&g, taps_row, taps_col, smem, frame, g1, g2, s, b, &pk);
+        roll_strip_call<LT>(&g, taps_row, taps_col, smem, frame, g1, g2, s, b, &pk, &mask);
     else
-        roll_strip<LT, RESP, ABL>(g, taps_row, taps_col, smem, frame, g1, g2, s, b, logical, pk);
+        roll_strip<LT, RESP, ABL>(g, taps_row, taps_col, smem, frame, g1, g2, s, b, logical, pk, mask);
     if (threadIdx.x == 0) {
+        g.part_mask[b * g.nslots + s] = mask;
         g.part_val[b * g.nslots + s] = pk.best;
         g.part_idx[b * g.nslots + s] = pk.idx;
         g.part_sec[b * g.nslots + s] = pk.second;
@@ -459,6 +514,8 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
 struct ChainGeo {
     LaunchGeo g;                         // frames = first frame of clip 0; guesses/frame_index unused
     const double *K64;                   // the reference's dense Float64 kernel (exact mode; null = off), dog_exact.hpp
+    const double *g64;                   // [2][l] Float64 Gaussians (the refinement's separable stage)
+    double dir, T64;
     int ref_cbw, ref_tile;               // refinement inside the kernel: window columns per block; pixel tile staged in LDS (the strips' LDS is its scratch)
     const f2 *taps_col_plain;            // (s·g₊[k], −s·g₋[k]) per tap: the refinement's column taps (taps_col is the roll kernel's paired table)
     const int *__restrict__ start;       // n_clips x 2, 1-based (row, col)
@@ -473,27 +530,25 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
     __shared__ int cur[2];
     __shared__ float pv[8], ps[8];
     __shared__ int pi[8];
-    __shared__ double lut[256], dred[8];
-    __shared__ int ired[8];
+    __shared__ unsigned long long pm[8];
     __shared__ int s_refine;
     __shared__ float s_max;
     const LaunchGeo &g = cg.g;
     const int tid = threadIdx.x, wave = tid >> 6, nst = blockDim.x >> 6;
-    const int c = blockIdx.x;
+    const int c_ = blockIdx.x;
     if (tid == 0) {
-        cur[0] = cg.start[2 * c];
-        cur[1] = cg.start[2 * c + 1];
+        cur[0] = cg.start[2 * c_];
+        cur[1] = cg.start[2 * c_ + 1];
         range_check(g.ex, cur[0], cur[1], LT / 2, g.fh, g.fw);
     }
-    if (cg.K64)
-        for (int p = tid; p < 256; p += blockDim.x) lut[p] = (double)p / 255.0;
     __syncthreads();
     for (int k = 0; k < cg.n_frames; ++k) {
         const int g1 = cur[0], g2 = cur[1];
-        const uint8_t *__restrict__ frame = g.frames + ((long long)c * cg.n_frames + k) * g.frame_stride;
+        const uint8_t *__restrict__ frame = g.frames + ((long long)c_ * cg.n_frames + k) * g.frame_stride;
         Peak pk;
-        roll_strip_call<LT>(&g, taps_row, taps_col, smem + wave * roll_lds_bytes(LT), frame, g1, g2, wave, 0, &pk);
-        if ((tid & 63) == 0) { pv[wave] = pk.best; pi[wave] = pk.idx; ps[wave] = pk.second; }
+        unsigned long long mask;
+        roll_strip_call<LT>(&g, taps_row, taps_col, smem + wave * roll_lds_bytes(LT), frame, g1, g2, wave, 0, &pk, &mask);
+        if ((tid & 63) == 0) { pv[wave] = pk.best; pi[wave] = pk.idx; ps[wave] = pk.second; pm[wave] = mask; }
         __syncthreads();
         if (tid == 0) {
             Peak w;
@@ -502,7 +557,7 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
             const int x = w.idx / g.n1, y = w.idx - x * g.n1;
             const int i = min(max(g1 - g.r1 + y, 1), g.fh);   // :60-61
             const int j = min(max(g2 - g.r2 + x, 1), g.fw);
-            int *o = cg.out_ij + 2 * ((long long)c * cg.n_frames + k);
+            int *o = cg.out_ij + 2 * ((long long)c_ * cg.n_frames + k);
             o[0] = i; o[1] = j;
             cur[0] = i; cur[1] = j;
             s_refine = cg.K64 && (w.best - w.second <= g.ex.T);
@@ -512,23 +567,33 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
         __syncthreads();
         if (s_refine) {
             // near-tie: the chain cannot go on before the reference's own arithmetic has decided (dog_exact.hpp);
-            // the strips' LDS is free between frames and holds the row-pass block
-            const int cbw = cg.ref_cbw;
-            Peak64 wk;
-            wk.best = -__builtin_huge_val();
-            wk.idx = 0x7fffffff;
-            for (int x0 = 0; x0 < g.n2; x0 += cbw) {
-                const Peak64 bk = refine_columns(blockDim.x, g, frame, g1, g2, x0, min(cbw, g.n2 - x0), s_max - g.ex.T, as_taps(taps_row),
-                                                 as_taps(cg.taps_col_plain), (k64_ptr)(unsigned long long)cg.K64,
-                                                 reinterpret_cast<f2 *>(smem), cg.ref_tile ? smem + refine_r_bytes(g.n1, LT, cbw) : nullptr, lut, ired,
-                                                 dred, false);
-                if (tid == 0) peak64_push(wk, bk.best, bk.idx);
-            }
+            // the strips' LDS is free between frames and is the refinement's scratch
+            RefineCtx c;
+            c.trow = as_taps(taps_row);
+            c.tcol = as_taps(cg.taps_col_plain);
+            c.K = (k64_ptr)(unsigned long long)cg.K64;
+            c.g64 = (k64_ptr)(unsigned long long)cg.g64;
+            c.dir = cg.dir;
+            c.T64 = cg.T64;
+            c.T = g.ex.T;
+            c.cbw = cg.ref_cbw;
+            c.use_tile = cg.ref_tile;
+            c.lds = smem;
+            const float thr = s_max - g.ex.T;
+            auto may = [&](int x0, int x1) { // strip s covers 64 columns from min(64 s, n2 − 64) (one partial strip when n2 < 64)
+                bool any = false;
+                for (int q = 0; q < nst; ++q) {
+                    const int lo = g.n2 >= ROLL_TW ? min(q * ROLL_TW, g.n2 - ROLL_TW) : 0, hi = lo + ROLL_TW;
+                    if (lo < x1 && hi > x0 && pv[q] >= thr && (pm[q] & column_bits(x0 - lo, x1 - lo))) any = true;
+                }
+                return any;
+            };
+            const int idx = refine_window(blockDim.x, g, frame, g1, g2, s_max, c, may);
             if (tid == 0) {
-                const int x = wk.idx / g.n1, y = wk.idx - x * g.n1;
+                const int x = idx / g.n1, y = idx - x * g.n1;
                 const int i = min(max(g1 - g.r1 + y, 1), g.fh);
                 const int j = min(max(g2 - g.r2 + x, 1), g.fw);
-                int *o = cg.out_ij + 2 * ((long long)c * cg.n_frames + k);
+                int *o = cg.out_ij + 2 * ((long long)c_ * cg.n_frames + k);
                 o[0] = i; o[1] = j;
                 cur[0] = i; cur[1] = j;
             }

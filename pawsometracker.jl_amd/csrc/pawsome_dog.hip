@@ -201,7 +201,6 @@ const Variant kVariants[] = {
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr size_t kMaxLds = 160 * 1024;
 constexpr int kThinMax = 6; // remainder columns done by dog_thin_kernel instead of one more strip
-constexpr int kFinishMaxS = 32; // dog_finish_kernel: at most this many workgroups share one window's refinement
 
 const Variant *find_variant(int id)
 {
@@ -241,6 +240,7 @@ struct pdog_tracker {
     f2 *d_taps_row = nullptr, *d_taps_col = nullptr;
     f2 *d_taps_roll = nullptr; // paired column-tap table of dog_roll.hpp
     float *d_part_val = nullptr, *d_part_sec = nullptr;
+    unsigned long long *d_part_mask = nullptr;
     int *d_part_idx = nullptr;
     int cap_windows = 0;
     // exact mode (dog_exact.hpp): windows whose two best FP32 responses lie within 2δ are re-decided in the
@@ -249,11 +249,13 @@ struct pdog_tracker {
     bool exact_all = false;           // pdog_set_exact(t, 2): refine every window with an infinite threshold (tests: the whole reference computation on the device)
     float exact_T = 0.f;              // 2δ
     double *d_K64 = nullptr;          // dir·(g₊⊗g₊ − g₋⊗g₋), l×l column-major, Float64 (:41-43)
+    double *d_g64 = nullptr;          // [2][l] the two normalised Gaussians in Float64 (the refinement's separable stage)
+    double exact_T64 = 0.0;           // 2δ64: separable Float64 against the reference's dense Float64
     unsigned long long *d_ref_stat = nullptr;
-    double *d_ref_pval = nullptr;     // [cap][kFinishMaxS] Float64 partial peaks of the finishing kernel's workgroups
-    int *d_ref_pidx = nullptr, *d_ref_done = nullptr;
-    int ref_cbw = 1, ref_nblk = 1;
-    bool ref_tile = false;            // the refinement kernel stages its block's pixels in LDS
+    int ref_cbw = 1;                  // window columns per block of the refinement
+    bool ref_tile = false;            // the refinement stages its block's pixels in LDS
+    int fused_ref_cbw = 1;            // the same for the refinement inside the fused kernel (its scratch is that kernel's LDS)
+    bool fused_ref_tile = false;
     // host-path staging (pdog_detect_host / chain seed)
     uint8_t *d_frame = nullptr;
     int32_t *d_small = nullptr; // [0..1] guess, [2..3] result
@@ -284,6 +286,27 @@ fused_fn_t fused_kernel_for(int L, bool resp);
 // partly masked group of 13 outputs must stay inside the zero-padded row.  nout outputs, l taps.
 int twopass_pitch(int nout, int L, int rows = HP_ROWS) { return (round_up(nout, rows == 8 ? 32 * 7 : 16 * 13) + L + 16) | 1; }
 
+// Exact mode's refinement (dog_exact.hpp) works on blocks of `cbw` window columns whose row-pass result (two doubles
+// per element in the Float64 stage) fits ≈24 KB of LDS; the block's pixels go to LDS too when everything fits 64 KB
+// (l ≲ 120): a candidate's chain then reads LDS instead of waiting for memory once per term.
+void setup_refine_geometry(pdog_tracker *t)
+{
+    const int NA = t->n1 + t->L - 1;
+    t->ref_cbw = std::max(1, std::min({8, t->n2, (int)(24576 / ((size_t)NA * 16))}));
+    t->ref_tile = refine_lds_bytes(t->n1, t->L, t->ref_cbw, true) <= 64 * 1024;
+    // inside the fused kernel the scratch is that kernel's own LDS (tile + RT, free by then): the widest block that fits it
+    t->fused_ref_cbw = 1;
+    t->fused_ref_tile = refine_lds_bytes(t->n1, t->L, 1, true) <= kMaxLds - 1024; // tiny windows: the scratch is larger than tile + RT
+    const size_t have = fused_lds_bytes(t->n1, t->n2, t->L);
+    for (int cbw = std::min(8, t->n2); cbw >= 1; --cbw)
+        if (refine_lds_bytes(t->n1, t->L, cbw, true) <= have) { t->fused_ref_cbw = cbw; t->fused_ref_tile = true; break; }
+}
+// dynamic LDS of the fused kernel: its tile + RT, or the scratch of the refinement it may run in the same memory
+size_t fused_total_lds(const pdog_tracker *t)
+{
+    return std::max(fused_lds_bytes(t->n1, t->n2, t->L), refine_lds_bytes(t->n1, t->L, t->fused_ref_cbw, t->fused_ref_tile));
+}
+
 int choose_variant(pdog_tracker *t, int forced)
 {
     const Variant *best = nullptr;
@@ -292,7 +315,7 @@ int choose_variant(pdog_tracker *t, int forced)
         const Variant &v = kVariants[i];
         if (forced >= 0 && v.id != forced) continue;
         if (v.fused) { // never the tracker's batch kernel unless forced; small batches and chains reach it below
-            if (forced == v.id && fused_lds_bytes(t->n1, t->n2, t->L) <= kMaxLds - 4096 && t->n2 + t->L - 1 <= 4 * FUSED_NT && t->fw >= 4) best = &v;
+            if (forced == v.id && fused_total_lds(t) <= kMaxLds - 1024 && t->n2 + t->L - 1 <= 4 * FUSED_NT && t->fw >= 4) best = &v;
             continue;
         }
         if (v.LT != 0 && v.LT != t->L) continue;
@@ -325,10 +348,10 @@ int choose_variant(pdog_tracker *t, int forced)
     t->thin_x0 = 0;
     t->forced_variant = forced >= 0;
     t->small_twopass = false;
-    t->fused_ok = fused_lds_bytes(t->n1, t->n2, t->L) <= kMaxLds - 4096 && t->n2 + t->L - 1 <= 4 * FUSED_NT && t->fw >= 4;
+    t->fused_ok = fused_total_lds(t) <= kMaxLds - 1024 && t->n2 + t->L - 1 <= 4 * FUSED_NT && t->fw >= 4;
     if (t->fused_ok) {
         for (bool resp : {false, true}) {
-            if (int rc = raise_lds_limit((const void *)fused_kernel_for(t->L, resp), fused_lds_bytes(t->n1, t->n2, t->L))) return rc;
+            if (int rc = raise_lds_limit((const void *)fused_kernel_for(t->L, resp), fused_total_lds(t))) return rc;
         }
     }
     if (best->fused) { t->nstrips = 1; return PDOG_OK; }
@@ -396,20 +419,16 @@ int ensure_capacity(pdog_tracker *t, int n)
     for (int i = 0; i < kNumVariants; ++i)
         if (!kVariants[i].fused) max_strips = std::max(max_strips, (t->n2 + kVariants[i].tw() - 1) / kVariants[i].tw() + kThinMax);
     max_strips = std::max(max_strips, (t->n2 + 7) / 8);
-    for (void *p : {(void *)t->d_part_val, (void *)t->d_part_idx, (void *)t->d_part_sec, (void *)t->d_ref_pval, (void *)t->d_ref_pidx,
-                    (void *)t->d_ref_done})
+    for (void *p : {(void *)t->d_part_val, (void *)t->d_part_idx, (void *)t->d_part_sec, (void *)t->d_part_mask})
         if (p) (void)hipFree(p);
     t->d_part_val = t->d_part_sec = nullptr;
     t->d_part_idx = nullptr;
-    t->d_ref_pval = nullptr; t->d_ref_pidx = nullptr; t->d_ref_done = nullptr;
+    t->d_part_mask = nullptr;
     t->cap_windows = 0;
     HIP_TRY(hipMalloc(&t->d_part_val, sizeof(float) * (size_t)n * max_strips));
     HIP_TRY(hipMalloc(&t->d_part_sec, sizeof(float) * (size_t)n * max_strips));
     HIP_TRY(hipMalloc(&t->d_part_idx, sizeof(int) * (size_t)n * max_strips));
-    HIP_TRY(hipMalloc(&t->d_ref_pval, sizeof(double) * (size_t)n * kFinishMaxS));
-    HIP_TRY(hipMalloc(&t->d_ref_pidx, sizeof(int) * (size_t)n * kFinishMaxS));
-    HIP_TRY(hipMalloc(&t->d_ref_done, sizeof(int) * (size_t)n));
-    HIP_TRY(hipMemset(t->d_ref_done, 0, sizeof(int) * (size_t)n));
+    HIP_TRY(hipMalloc(&t->d_part_mask, sizeof(unsigned long long) * (size_t)n * max_strips));
     t->cap_windows = n;
     return PDOG_OK;
 }
@@ -446,29 +465,32 @@ ExactCtl exact_ctl(const pdog_tracker *t)
     return x;
 }
 
-// The last kernel of a batch (dog_exact.hpp): strip combine, index map and clamp (:58-61) for every window, and the
-// Float64 refinement of exact mode for the windows that need it.  A large batch gets one workgroup per window (the
-// refinement of the few flagged windows spreads over the GPU by itself); a small one splits each window's column
-// blocks over up to kFinishMaxS workgroups so that a single flagged window does not wait for one CU.
-// With done_flag set the kernel also publishes the host functor's ticket with window 0's final answer.
-int launch_finish(pdog_tracker *t, const LaunchGeo &g, int32_t *d_out_ij, int32_t *d_done_flag, int32_t done_value)
+// The last kernel of a batch (dog_exact.hpp): strip combine, index map and clamp (:58-61) for every window — one
+// workgroup each — and the refinement of exact mode for the windows that need it.  `slot_w`, `slot_last`: how the
+// partial slots the main kernels wrote map to window columns (the refinement only rescans column blocks whose slot
+// can hold a near-maximal pixel).  With done_flag set the kernel also publishes the host functor's ticket with
+// window 0's final answer.
+int launch_finish(pdog_tracker *t, const LaunchGeo &g, int slot_w, int slot_last, int32_t *d_out_ij, int32_t *d_done_flag, int32_t done_value,
+                  bool use_mask = false)
 {
     FinishGeo fg;
     fg.g = g;
     fg.K64 = t->exact ? t->d_K64 : nullptr;
+    fg.g64 = t->d_g64;
+    fg.dir = t->darker ? -1.0 : 1.0;
+    fg.T64 = t->exact_T64;
     fg.cbw = t->ref_cbw;
-    fg.nblk = t->ref_nblk;
     fg.use_tile = t->ref_tile ? 1 : 0;
-    fg.S = (int)std::max<long long>(1, std::min<long long>(std::min(kFinishMaxS, t->ref_nblk), 2048 / std::max(1, g.n)));
-    fg.part_val = t->d_ref_pval;
-    fg.part_idx = t->d_ref_pidx;
-    fg.part_done = t->d_ref_done;
+    fg.slot_w = slot_w;
+    fg.slot_last = slot_last;
+    fg.nmain = g.nslots - g.nthin;
+    fg.thin_x0 = g.thin_x0;
+    fg.use_mask = use_mask ? 1 : 0;
     fg.out_ij = d_out_ij;
     fg.done_flag = d_done_flag;
     fg.done_value = done_value;
     const size_t lds = t->exact ? refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_tile) : 0;
-    hipLaunchKernelGGL(dog_finish_kernel, dim3((unsigned)((long long)g.n * fg.S)), dim3(REFINE_NT), lds, t->stream, fg,
-                       (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
+    hipLaunchKernelGGL(dog_finish_kernel, dim3(g.n), dim3(REFINE_NT), lds, t->stream, fg, (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
     HIP_TRY(hipGetLastError());
     return PDOG_OK;
 }
@@ -515,8 +537,13 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     fg.done_value = done_value;
     fg.progress = progress ? 1 : 0;
     fg.K64 = t->exact ? t->d_K64 : nullptr;
+    fg.g64 = t->d_g64;
+    fg.dir = t->darker ? -1.0 : 1.0;
+    fg.T64 = t->exact_T64;
+    fg.ref_cbw = t->fused_ref_cbw;
+    fg.ref_tile = t->fused_ref_tile ? 1 : 0;
     g.ex = exact_ctl(t);
-    const size_t lds = fused_lds_bytes(t->n1, t->n2, t->L);
+    const size_t lds = fused_total_lds(t);
     typedef fused_fn_t fused_fn;
     fused_fn fn = fused_kernel_for(t->L, d_out_resp != nullptr);
 #ifdef PDOG_ABLATIONS
@@ -549,6 +576,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     g.part_val = t->d_part_val;
     g.part_idx = t->d_part_idx;
     g.part_sec = t->d_part_sec;
+    g.part_mask = t->d_part_mask;
     g.ex = exact_ctl(t);
     g.fh = FH; g.fw = FW; g.r1 = t->r1; g.r2 = t->r2; g.n1 = t->n1; g.n2 = t->n2;
     g.L = t->L; g.fill = t->fill; g.nstrips = t->nstrips; g.n = n;
@@ -623,7 +651,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
             else
                 hipLaunchKernelGGL((dog_hpass_kernel<7, 16, false, 8>), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             HIP_TRY(hipGetLastError());
-            return launch_finish(t, g, d_out_ij, d_done_flag, done_value);
+            return launch_finish(t, g, hr, 1 << 30, d_out_ij, d_done_flag, done_value);
         }
         if (lowlat) {
             if (!t->d_counter) {
@@ -662,7 +690,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
                 hipLaunchKernelGGL((dog_hpass_kernel<13, 16, false>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             HIP_TRY(hipGetLastError());
         }
-        return launch_finish(t, g, d_out_ij, nullptr, 0);
+        return launch_finish(t, g, hr, 1 << 30, d_out_ij, nullptr, 0);
     }
     const int grid = round_up(g.nblocks, 8);
     if (t->nthin) {
@@ -686,7 +714,9 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
                        (const f2 *)t->d_taps_row, (const f2 *)(v.roll ? t->d_taps_roll : t->d_taps_col));
     HIP_TRY(hipGetLastError());
     if (t->nthin) HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0)); // join before the strip combine
-    return launch_finish(t, g, d_out_ij, nullptr, 0);
+    // roll: 64-column strips over the first `covered` columns, the last one shifted left to stay inside; ring: tw() columns each
+    const int covered = t->nthin ? t->thin_x0 : t->n2;
+    return launch_finish(t, g, v.tw(), v.roll ? std::max(0, covered - v.tw()) : (1 << 30), d_out_ij, nullptr, 0, v.roll);
 }
 
 } // namespace
@@ -804,6 +834,7 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
     t->fill = fill;                                // :47
     if ((long long)t->n1 * t->n2 > 0x3fffffffLL) { delete t; return fail(PDOG_E_ARG, "pdog_create: window too large"); }
 
+    setup_refine_geometry(t);
     int rc = choose_variant(t, -1);
     if (rc) { delete t; return rc; }
 
@@ -870,14 +901,16 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
         t->exact_T = std::nextafter((float)(2.0 * delta), 1.0f);
         CREATE_TRY(hipMalloc(&t->d_ref_stat, sizeof(unsigned long long)));
         CREATE_TRY(hipMemset(t->d_ref_stat, 0, sizeof(unsigned long long)));
-        // refinement work items: column blocks whose row-pass result fits ≈20 KB of LDS
-        const int NA = t->n1 + t->L - 1;
-        t->ref_cbw = std::max(1, std::min(8, (int)(20480 / ((size_t)NA * sizeof(f2)))));
-        t->ref_nblk = (t->n2 + t->ref_cbw - 1) / t->ref_cbw;
-        t->exact = !t->sw.no_exact && refine_lds_bytes(t->n1, t->L, 1) <= kMaxLds - 8192;
-        // the block's pixels go to LDS too when they fit beside the row-pass block (l ≲ 120): a candidate's chain then
-        // reads LDS instead of waiting for memory once per term
-        t->ref_tile = refine_lds_bytes(t->n1, t->L, t->ref_cbw, true) <= 64 * 1024;
+        {
+            std::vector<double> g2(2 * (size_t)t->L);
+            std::copy(gp.begin(), gp.end(), g2.begin());
+            std::copy(gm.begin(), gm.end(), g2.begin() + t->L);
+            CREATE_TRY(hipMalloc(&t->d_g64, sizeof(double) * g2.size()));
+            CREATE_TRY(hipMemcpy(t->d_g64, g2.data(), sizeof(double) * g2.size(), hipMemcpyHostToDevice));
+        }
+        // separable Float64 vs the reference's dense Float64 (l² sequential roundings): both within δ64 of the exact value
+        t->exact_T64 = 2.0 * std::ldexp(1.0, -53) * (2.1 * t->L * t->L + 8.0 * t->L + 64.0);
+        t->exact = !t->sw.no_exact && refine_lds_bytes(t->n1, t->L, 1, false) <= kMaxLds - 8192;
         if (raise_lds_limit((const void *)dog_finish_kernel, refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_tile))) { pdog_destroy(t); return PDOG_E_HIP; }
     }
 #undef CREATE_TRY
@@ -895,8 +928,8 @@ int pdog_destroy(pdog_tracker *t)
     if (t->d_taps_row) (void)hipFree(t->d_taps_row);
     if (t->d_taps_col) (void)hipFree(t->d_taps_col);
     if (t->d_taps_roll) (void)hipFree(t->d_taps_roll);
-    for (void *p : {(void *)t->d_part_val, (void *)t->d_part_idx, (void *)t->d_part_sec, (void *)t->d_ref_pval, (void *)t->d_ref_pidx,
-                    (void *)t->d_ref_done, (void *)t->d_K64, (void *)t->d_ref_stat})
+    for (void *p : {(void *)t->d_part_val, (void *)t->d_part_idx, (void *)t->d_part_sec, (void *)t->d_part_mask, (void *)t->d_K64, (void *)t->d_g64,
+                    (void *)t->d_ref_stat})
         if (p) (void)hipFree(p);
     if (t->d_frame) (void)hipFree(t->d_frame);
     if (t->d_small) (void)hipFree(t->d_small);
@@ -1013,7 +1046,7 @@ int pdog_sync(pdog_tracker *t)
 int pdog_set_exact(pdog_tracker *t, int on)
 {
     if (!t) return fail(PDOG_E_ARG, "pdog_set_exact: null tracker");
-    if (on && refine_lds_bytes(t->n1, t->L, 1) > kMaxLds - 8192)
+    if (on && refine_lds_bytes(t->n1, t->L, 1, false) > kMaxLds - 8192)
         return fail(PDOG_E_ARG, "pdog_set_exact: window too tall for the refinement's LDS block");
     HIP_TRY(hipStreamSynchronize(t->stream));
     t->exact = on != 0;
@@ -1414,6 +1447,9 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
         cg.n_frames = n_frames;
         g.ex = exact_ctl(t);
         cg.K64 = t->exact ? t->d_K64 : nullptr;
+        cg.g64 = t->d_g64;
+        cg.dir = t->darker ? -1.0 : 1.0;
+        cg.T64 = t->exact_T64;
         cg.taps_col_plain = t->d_taps_col;
         // the strips' LDS doubles as the refinement's scratch (row-pass block + pixel tile when they fit in 64 KB)
         cg.ref_cbw = std::min(t->n2, t->ref_cbw);
