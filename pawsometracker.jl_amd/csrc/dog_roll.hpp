@@ -80,7 +80,12 @@ __device__ __forceinline__ void roll_row_pass(f2 (&acc)[ROLL_P], const float *a,
 {
     constexpr int P = ROLL_P, H = L / 2, U = 4, NP = P / 2;
     constexpr int W = 2 * (NP - 1) + U; // pairs per window: n = base + (2*op + u)
-    auto pair_at = [&](int n) { return f2{a[n], a[n + 1]}; };
+    // Pairs at odd n come through a second, laundered pointer: seen as the same memory the compiler loads every
+    // float once and assembles the odd pairs with v_pk_mov_b32 / v_mov_b32 (≈50 VALU slots per sub-chunk); the LDS
+    // pipe has room for the extra ds_read2_b32, the VALU has not.
+    const float *ao = a;
+    asm volatile("" : "+v"(ao));
+    auto pair_at = [&](int n) { return (n & 1) ? f2{ao[n], ao[n + 1]} : f2{a[n], a[n + 1]}; };
     f2 lo[W], hi[W];
 #pragma unroll
     for (int j = 0; j < W; ++j) {
@@ -165,94 +170,60 @@ __host__ __device__ constexpr int roll_col_table_len(int L) { return roll_col_bl
 // phase equals the sub-chunk number, so the shortened bodies are static instances with no branch inside.
 __host__ __device__ constexpr int roll_prologue_blocks(int sc) { return 2 * sc + 2; }
 __host__ __device__ constexpr int roll_prologue_len(int L) { return (roll_col_blocks(L) - 2 + 1) / 2; } // sub-chunks with fewer blocks than the full body
-// One tap block of the column pass: requests the next block's taps, then this block's FMAs for the 8 rows.
-template <int L, int SC, int NQB, int qb>
-__device__ __forceinline__ void roll_col_block(f2 (&acc2)[roll_slots(L) / 2], const f2 (&rv)[ROLL_CH], f2 (&tn)[4 * ROLL_QB], tap_ptr &tb)
-{
-    constexpr int S = roll_slots(L), CH = ROLL_CH, QB = ROLL_QB;
-    f2 t[4 * QB];
-#pragma unroll
-    for (int j = 0; j < 4 * QB; ++j) t[j] = tn[j];
-    if (qb + 1 < NQB) {
-        tb = pin_taps(tb);
-        const tap_ptr tnext = tb + (qb + 1) * 4 * QB;
-#pragma unroll
-        for (int j = 0; j < 4 * QB; ++j) tn[j] = tnext[j];
-    }
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        const int par = i & 1;
-        const int amod = CH * SC + i;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-#pragma unroll
-            for (int m = 0; m < QB; ++m) {
-                const int tt = par + 2 * (QB * qb + m); // taps (tt, tt-1)
-                if (tt - 1 <= L - 1) {
-                    const int slot = ((amod - tt) % S + S) % S; // even
-                    const float r = c ? rv[i].y : rv[i].x;
-                    // An even row's pair (T[0], T[−1] = 0) is the FIRST term of outputs (a, a+1) — the slots the
-                    // sub-chunk S rows earlier emitted: a multiply starts them from scratch (no reset instructions;
-                    // output a+1 starts at ±0 and meets its own first term, row a+1's T[0], later in this block).
-                    if (tt == 0 && c == 0)
-                        acc2[slot / 2] = f2{r, r} * t[(par * 2 + c) * QB + m];
-                    else
-                        acc2[slot / 2] = fma_bcast(r, t[(par * 2 + c) * QB + m], acc2[slot / 2]);
-                }
-            }
-        }
-    }
-    // pin exactly the pairs this block touched (pinning idle ones makes the allocator copy them)
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-#pragma unroll
-        for (int m = 0; m < QB; ++m) {
-            const int tt = (i & 1) + 2 * (QB * qb + m);
-            if (tt - 1 <= L - 1) pin_acc(acc2[(((CH * SC + i - tt) % S + S) % S) / 2]);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// QHI < roll_col_blocks(L): a PROLOGUE body, blocks 0 … QHI−1 only (see above).  Full bodies (QHI = all blocks) are
-// entered at block `qlo` through a switch that falls through to the end: the last l−1 input rows have no output
-// below row n1−1 to feed, rows a … a+7 only need taps t ≥ a − (n1−1), so the leading blocks are skipped with ONE
-// scalar jump and no branch between blocks (qlo = 0 everywhere else).
 template <int L, int SC, int QHI = roll_col_blocks(L)>
-__device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], const f2 (&rv)[ROLL_CH], tap_ptr table, int qlo)
+__device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], const f2 (&rv)[ROLL_CH], tap_ptr table)
 {
     constexpr int S = roll_slots(L), CH = ROLL_CH, QB = ROLL_QB, NQB = QHI;
     static_assert(QHI >= 1 && QHI <= roll_col_blocks(L), "tap-block bound out of range");
     static_assert(S % 2 == 0 && (CH * SC) % 2 == 0, "pairing needs even slot counts");
-    static_assert(roll_col_blocks(L) <= 28, "extend the entry switch");
     f2 tn[4 * QB];
     tap_ptr tb = pin_taps(table);
-    if constexpr (QHI < roll_col_blocks(L)) {
 #pragma unroll
-        for (int j = 0; j < 4 * QB; ++j) tn[j] = tb[j];
-        auto run = [&](auto self, auto QBc) {
-            constexpr int qb = decltype(QBc)::value;
-            if constexpr (qb < NQB) {
-                roll_col_block<L, SC, NQB, qb>(acc2, rv, tn, tb);
-                self(self, std::integral_constant<int, qb + 1>{});
-            }
-        };
-        run(run, std::integral_constant<int, 0>{});
-    } else {
-        const tap_ptr t0 = tb + qlo * (4 * QB); // the entry block's taps
+    for (int j = 0; j < 4 * QB; ++j) tn[j] = tb[j];
 #pragma unroll
-        for (int j = 0; j < 4 * QB; ++j) tn[j] = t0[j];
-#define PDOG_BLK(k)                                                                  \
-    case k:                                                                          \
-        if constexpr ((k) < NQB) roll_col_block<L, SC, NQB, ((k) < NQB ? (k) : 0)>(acc2, rv, tn, tb); \
-        [[fallthrough]];
-        switch (qlo) {
-            PDOG_BLK(0) PDOG_BLK(1) PDOG_BLK(2) PDOG_BLK(3) PDOG_BLK(4) PDOG_BLK(5) PDOG_BLK(6) PDOG_BLK(7) PDOG_BLK(8) PDOG_BLK(9)
-            PDOG_BLK(10) PDOG_BLK(11) PDOG_BLK(12) PDOG_BLK(13) PDOG_BLK(14) PDOG_BLK(15) PDOG_BLK(16) PDOG_BLK(17) PDOG_BLK(18)
-            PDOG_BLK(19) PDOG_BLK(20) PDOG_BLK(21) PDOG_BLK(22) PDOG_BLK(23) PDOG_BLK(24) PDOG_BLK(25) PDOG_BLK(26) PDOG_BLK(27)
-        default: break;
+    for (int qb = 0; qb < NQB; ++qb) {
+        f2 t[4 * QB];
+#pragma unroll
+        for (int j = 0; j < 4 * QB; ++j) t[j] = tn[j];
+        if (qb + 1 < NQB) {
+            tb = pin_taps(tb);
+            const tap_ptr tnext = tb + (qb + 1) * 4 * QB;
+#pragma unroll
+            for (int j = 0; j < 4 * QB; ++j) tn[j] = tnext[j];
         }
-#undef PDOG_BLK
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int par = i & 1;
+            const int amod = CH * SC + i;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int m = 0; m < QB; ++m) {
+                    const int tt = par + 2 * (QB * qb + m); // taps (tt, tt-1)
+                    if (tt - 1 <= L - 1) {
+                        const int slot = ((amod - tt) % S + S) % S; // even
+                        const float r = c ? rv[i].y : rv[i].x;
+                        // An even row's pair (T[0], T[−1] = 0) is the FIRST term of outputs (a, a+1) — the slots the
+                        // sub-chunk S rows earlier emitted: a multiply starts them from scratch (no reset instructions;
+                        // output a+1 starts at ±0 and meets its own first term, row a+1's T[0], later in this block).
+                        if (tt == 0 && c == 0)
+                            acc2[slot / 2] = f2{r, r} * t[(par * 2 + c) * QB + m];
+                        else
+                            acc2[slot / 2] = fma_bcast(r, t[(par * 2 + c) * QB + m], acc2[slot / 2]);
+                    }
+                }
+            }
+        }
+        // pin exactly the pairs this block touched (pinning idle ones makes the allocator copy them)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+#pragma unroll
+            for (int m = 0; m < QB; ++m) {
+                const int tt = (i & 1) + 2 * (QB * qb + m);
+                if (tt - 1 <= L - 1) pin_acc(acc2[(((CH * SC + i - tt) % S + S) % S) / 2]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -381,11 +352,9 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
 #pragma unroll
         for (int i = 0; i < CH; ++i) rv[i] = Rb[i * ROLL_PR + lane];
         const int phase = sc % NBODY;
-        // rows a = CH·sc … +7 need taps t ≥ a − (n1−1); block qb holds taps 4qb−1 … 4qb+3: blocks below qlo feed nothing
-        const int qlo = (ABL == 0) ? min(roll_col_blocks(L) - 1, max(0, (sc * CH - g.n1 - 2 + 3) >> 2)) : 0;
         auto emit = [&](auto SCc, auto QHIc) {
             constexpr int SC = decltype(SCc)::value, QHI = decltype(QHIc)::value;
-            if (!(ABL & 1)) roll_col_body<L, SC, QHI>(acc2, rv, tcol, qlo);
+            if (!(ABL & 1)) roll_col_body<L, SC, QHI>(acc2, rv, tcol);
             // outputs y = a − (l−1) for the 8 rows of this sub-chunk are complete.  A lane owns ONE
             // column and meets its rows in increasing y (= increasing column-major index), so a strict
             // '>' keeps the first maximum of the lane (findmax, :59); ties between lanes and strips
