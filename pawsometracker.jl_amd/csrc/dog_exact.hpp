@@ -353,22 +353,25 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
-    if (tid == 0) {
+    if (tid < 64) { // wave 0: the slots' loads go out together (one memory round trip), then a shuffle merge
         Peak pk;
         peak_init(pk);
-        for (int s = 0; s < g.nslots; ++s) peak_merge(pk, g.part_val[b * g.nslots + s], g.part_idx[b * g.nslots + s], g.part_sec[b * g.nslots + s]);
-        const bool rf = fg.K64 && (pk.best - pk.second <= g.ex.T);
-        range_check(g.ex, g1, g2, g.L >> 1, g.fh, g.fw);
-        if (rf) {
-            atomicAdd(g.ex.stat, 1ull);
-        } else {
-            const int x = pk.idx / g.n1, y = pk.idx - x * g.n1;
-            fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);       // :60-61
-            fg.out_ij[2 * b + 1] = min(max(g2 - g.r2 + x, 1), g.fw);
-            if (fg.done_flag && b == 0) __hip_atomic_store(fg.done_flag, fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int s = tid; s < g.nslots; s += 64) peak_merge(pk, g.part_val[b * g.nslots + s], g.part_idx[b * g.nslots + s], g.part_sec[b * g.nslots + s]);
+        peak_wave_reduce(pk);
+        if (tid == 0) {
+            const bool rf = fg.K64 && (pk.best - pk.second <= g.ex.T);
+            range_check(g.ex, g1, g2, g.L >> 1, g.fh, g.fw);
+            if (rf) {
+                atomicAdd(g.ex.stat, 1ull);
+            } else {
+                const int x = pk.idx / g.n1, y = pk.idx - x * g.n1;
+                fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);       // :60-61
+                fg.out_ij[2 * b + 1] = min(max(g2 - g.r2 + x, 1), g.fw);
+                if (fg.done_flag && b == 0) __hip_atomic_store(fg.done_flag, fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            s_refine = rf;
+            s_max = pk.best;
         }
-        s_refine = rf;
-        s_max = pk.best;
     }
     __syncthreads();
     if (!s_refine) return;

@@ -655,9 +655,18 @@ __global__ __launch_bounds__(256) void dog_thin_kernel(const LaunchGeo g, const 
             }
         }
         f2 acc = f2{0.f, 0.f};
+        // taps in blocks of 8 behind a base pointer re-pinned per block: left to itself the compiler hoists all 33
+        // loop-invariant tap pairs out of the row loop and spills them (400 SGPR spills, half of this kernel's VALU slots)
+        tap_ptr tb = trow;
 #pragma unroll
-        for (int k = 0; k < H; ++k) acc = fma_bcast(v[k] + v[L - 1 - k], trow[k], acc);
-        acc = fma_bcast(v[H], trow[H], acc);
+        for (int k0 = 0; k0 < H; k0 += 8) {
+            tb = pin_taps(tb);
+#pragma unroll
+            for (int k = k0; k < k0 + 8; ++k)
+                if (k < H) acc = fma_bcast(v[k] + v[L - 1 - k], tb[k], acc);
+        }
+        tb = pin_taps(tb);
+        acc = fma_bcast(v[H], tb[H], acc);
         Rc[a] = acc;
     }
     __syncthreads();

@@ -287,13 +287,13 @@ fused_fn_t fused_kernel_for(int L, bool resp);
 int twopass_pitch(int nout, int L, int rows = HP_ROWS) { return (round_up(nout, rows == 8 ? 32 * 7 : 16 * 13) + L + 16) | 1; }
 
 // Exact mode's refinement (dog_exact.hpp) works on blocks of `cbw` window columns whose row-pass result (two doubles
-// per element in the Float64 stage) fits ≈24 KB of LDS; the block's pixels go to LDS too when everything fits 64 KB
-// (l ≲ 120): a candidate's chain then reads LDS instead of waiting for memory once per term.
+// per element in the Float64 stage) fits ≈24 KB of LDS; the block's pixels go to LDS too when everything fits 100 KB
+// (l ≲ 150): a candidate's chain then reads LDS instead of waiting for memory once per term.
 void setup_refine_geometry(pdog_tracker *t)
 {
     const int NA = t->n1 + t->L - 1;
     t->ref_cbw = std::max(1, std::min({8, t->n2, (int)(24576 / ((size_t)NA * 16))}));
-    t->ref_tile = refine_lds_bytes(t->n1, t->L, t->ref_cbw, true) <= 64 * 1024;
+    t->ref_tile = refine_lds_bytes(t->n1, t->L, t->ref_cbw, true) <= 100 * 1024; // (one workgroup per CU beyond 80 KB: fine for a kernel whose blocks mostly exit at once)
     // inside the fused kernel the scratch is that kernel's own LDS (tile + RT, free by then): the widest block that fits it
     t->fused_ref_cbw = 1;
     t->fused_ref_tile = refine_lds_bytes(t->n1, t->L, 1, true) <= kMaxLds - 1024; // tiny windows: the scratch is larger than tile + RT
@@ -1451,10 +1451,15 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
         cg.dir = t->darker ? -1.0 : 1.0;
         cg.T64 = t->exact_T64;
         cg.taps_col_plain = t->d_taps_col;
-        // the strips' LDS doubles as the refinement's scratch (row-pass block + pixel tile when they fit in 64 KB)
-        cg.ref_cbw = std::min(t->n2, t->ref_cbw);
-        cg.ref_tile = t->ref_tile ? 1 : 0;
-        const size_t lds = std::max((size_t)chain_strips * roll_lds_bytes(v.LT), refine_lds_bytes(t->n1, t->L, cg.ref_cbw, t->ref_tile));
+        // the strips' LDS doubles as the refinement's scratch: the widest block (with its pixel tile if possible) that
+        // fits what the strips need anyway, so that exact mode does not cost the chain kernel occupancy
+        const size_t base = std::max((size_t)chain_strips * roll_lds_bytes(v.LT), refine_lds_bytes(t->n1, t->L, 1, false));
+        cg.ref_cbw = 1;
+        cg.ref_tile = 0;
+        for (int tile = 1; tile >= 0 && cg.ref_cbw == 1 && !cg.ref_tile; --tile)
+            for (int cbw = std::min(t->n2, t->ref_cbw); cbw >= 1; --cbw)
+                if (refine_lds_bytes(t->n1, t->L, cbw, tile != 0) <= base) { cg.ref_cbw = cbw; cg.ref_tile = tile; break; }
+        const size_t lds = base;
         if (int rc = raise_lds_limit((const void *)v.chain, lds)) return rc;
         hipLaunchKernelGGL(v.chain, dim3(n_clips), dim3(64 * chain_strips), lds, t->stream, cg,
                            (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_roll);
