@@ -150,7 +150,9 @@ struct RefineCtx {
 
 // `may(x0, x1)`: wave-uniform, false only if no pixel of window columns [x0, x1) can reach M − T.
 // Returns the window's answer (column-major index) in thread 0.
-template <typename May>
+// TILE: the block's pixels are staged in LDS (c.use_tile must agree); a compile-time choice so that a kernel that only
+// ever uses one of the two paths (the fused kernel always has room for the tile) does not carry the other's registers.
+template <bool TILE, typename May>
 __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, const uint8_t *__restrict__ frame, int g1, int g2, float M,
                                              const RefineCtx &c, May may)
 {
@@ -167,7 +169,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
     unsigned char *rbase = c.lds + refine_fixed_bytes();
     f2 *R32 = reinterpret_cast<f2 *>(rbase);
     double *R64 = reinterpret_cast<double *>(rbase);
-    uint8_t *tile = c.use_tile ? rbase + refine_r_bytes(g.n1, L, c.cbw) : nullptr;
+    uint8_t *const tile = TILE ? rbase + refine_r_bytes(g.n1, L, c.cbw) : nullptr;
 
     for (int p = tid; p < 256; p += NT) lut[p] = (double)p / 255.0;
     if (tid < 4) cnt[tid] = 0;
@@ -191,7 +193,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
             const int ncol = min(c.cbw, g.n2 - x0);
             if (!may(x0, x0 + ncol)) continue;
             const int tp = refine_tile_pitch(ncol, L), tw = ncol + L - 1;
-            if (tile) {
+            if constexpr (TILE) {
                 for (int e = tid; e < NA * tw; e += NT) {
                     const int a = e / tw, cc = e - a * tw;
                     const int gi = ti0 + a, gj = wj0 + x0 + cc;
@@ -201,17 +203,60 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                 }
                 __syncthreads();
             }
-            auto pixel = [&](int a, int cc) -> int { // tile row a, block column cc (0 … ncol+l−2)
-                if (tile) return tile[a * tp + cc];
-                const int gi = ti0 + a, gj = wj0 + x0 + cc;
-                return (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) ? frame[(long long)gi * g.row_stride + gj] : g.fill;
+            // One tile row without an LDS tile (long kernels): the thread that owns the row streams it once, 16 taps
+            // at a time — 24 bytes as 6 dwords when the whole stretch lies inside the frame row — and feeds all ncol ≤ 8
+            // outputs from registers (a byte load per tap and output would make this pass hundreds of µs).
+            auto row_chunk = [&](int a, int k0, int (&px)[24]) {
+                const int gi = ti0 + a, gj0 = wj0 + x0 + k0;
+                const bool rowok = gi >= 0 && gi < g.fh;
+                if (rowok && gj0 >= 0 && gj0 + 24 <= g.fw) {
+                    const uint8_t *src = frame + (long long)gi * g.row_stride + gj0;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        uint32_t w;
+                        __builtin_memcpy(&w, src + 4 * q, 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) px[4 * q + i] = (int)((w >> (8 * i)) & 0xffu);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 24; ++i) {
+                        const int gj = gj0 + i;
+                        px[i] = (rowok && gj >= 0 && gj < g.fw) ? (int)frame[(long long)gi * g.row_stride + gj] : g.fill;
+                    }
+                }
             };
             // stage 1, row pass: R±[a][x] = Σ_k ĝ±[k]·(pixel − dc), k ascending
-            for (int e = tid; e < NA * ncol; e += NT) {
-                const int a = e / ncol, x = e - a * ncol;
-                f2 acc = f2{0.f, 0.f};
-                for (int k = 0; k < L; ++k) acc = fma_bcast((float)(pixel(a, x + k) - dc), c.trow[k], acc);
-                R32[e] = acc;
+            if constexpr (TILE) {
+                for (int e = tid; e < NA * ncol; e += NT) {
+                    const int a = e / ncol, x = e - a * ncol;
+                    const uint8_t *src = tile + a * tp + x;
+                    f2 acc = f2{0.f, 0.f};
+                    for (int k = 0; k < L; ++k) acc = fma_bcast((float)((int)src[k] - dc), c.trow[k], acc);
+                    R32[e] = acc;
+                }
+            } else {
+                for (int a = tid; a < NA; a += NT) {
+                    f2 acc[8];
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) acc[x] = f2{0.f, 0.f};
+                    for (int k0 = 0; k0 < L; k0 += 16) {
+                        int px[24];
+                        row_chunk(a, k0, px);
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            if (k0 + u < L) {
+                                const f2 t = c.trow[k0 + u];
+#pragma unroll
+                                for (int x = 0; x < 8; ++x)
+                                    if (x < ncol) acc[x] = fma_bcast((float)(px[u + x] - dc), t, acc[x]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int x = 0; x < 8; ++x)
+                        if (x < ncol) R32[a * ncol + x] = acc[x];
+                }
             }
             __syncthreads();
             const int first = min(cnt[0], REFINE_CAP);
@@ -229,7 +274,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                 if (acc >= thr) {
                     const int lin = (x0 + x) * g.n1 + y;
                     if (direct) {
-                        const double F = tile ? exact_patch((const uint8_t *)(tile + y * tp + x), (long long)tp, L, c.K, lut)
+                        const double F = TILE ? exact_patch((const uint8_t *)(tile + y * tp + x), (long long)tp, L, c.K, lut)
                                               : exact_pixel(frame, g.row_stride, g.fh, g.fw, g.fill, ti0 + y, wj0 + x0 + x, L, c.K, lut);
                         peak64_push(pk, F, lin);
                     } else {
@@ -242,16 +287,44 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
             const int last = min(cnt[0], REFINE_CAP);
             if (!direct && last > first && !cnt[1]) {
                 // stage 2: both Gaussians' row sums in Float64 for this block's columns (R32 is dead: same memory) …
-                for (int e = tid; e < NA * ncol; e += NT) {
-                    const int a = e / ncol, x = e - a * ncol;
-                    double sp = 0.0, sm = 0.0;
-                    for (int k = 0; k < L; ++k) {
-                        const double v = lut[pixel(a, x + k)];
-                        sp = __builtin_fma(c.g64[k], v, sp);
-                        sm = __builtin_fma(c.g64[L + k], v, sm);
+                if constexpr (TILE) {
+                    for (int e = tid; e < NA * ncol; e += NT) {
+                        const int a = e / ncol, x = e - a * ncol;
+                        const uint8_t *src = tile + a * tp + x;
+                        double sp = 0.0, sm = 0.0;
+                        for (int k = 0; k < L; ++k) {
+                            const double v = lut[src[k]];
+                            sp = __builtin_fma(c.g64[k], v, sp);
+                            sm = __builtin_fma(c.g64[L + k], v, sm);
+                        }
+                        R64[2 * e] = sp;
+                        R64[2 * e + 1] = sm;
                     }
-                    R64[2 * e] = sp;
-                    R64[2 * e + 1] = sm;
+                } else {
+                    for (int a = tid; a < NA; a += NT) {
+                        double sp[8], sm[8];
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) sp[x] = sm[x] = 0.0;
+                        for (int k0 = 0; k0 < L; k0 += 16) {
+                            int px[24];
+                            row_chunk(a, k0, px);
+                            double v[24];
+#pragma unroll
+                            for (int i = 0; i < 24; ++i) v[i] = lut[px[i]];
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) {
+                                if (k0 + u < L) {
+                                    const double gp = c.g64[k0 + u], gm = c.g64[L + k0 + u];
+#pragma unroll
+                                    for (int x = 0; x < 8; ++x)
+                                        if (x < ncol) { sp[x] = __builtin_fma(gp, v[u + x], sp[x]); sm[x] = __builtin_fma(gm, v[u + x], sm[x]); }
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int x = 0; x < 8; ++x)
+                            if (x < ncol) { R64[2 * (a * ncol + x)] = sp[x]; R64[2 * (a * ncol + x) + 1] = sm[x]; }
+                    }
                 }
                 __syncthreads();
                 // … and the new candidates' values dir·(Σ g₊[t]·R₊[y+t] − Σ g₋[t]·R₋[y+t])
@@ -401,7 +474,7 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
         }
         return any;
     };
-    const int idx = refine_window(NT, g, frame, g1, g2, s_max, c, may);
+    const int idx = fg.use_tile ? refine_window<true>(NT, g, frame, g1, g2, s_max, c, may) : refine_window<false>(NT, g, frame, g1, g2, s_max, c, may);
     if (tid == 0) {
         const int x = idx / g.n1, y = idx - x * g.n1;
         fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);

@@ -36,7 +36,7 @@ struct FusedGeo {
     const double *K64;   // the reference's dense Float64 kernel, l×l column-major (exact mode, dog_exact.hpp); null = off
     const double *g64;   // [2][l] Float64 Gaussians (the refinement's separable stage)
     double dir, T64;
-    int ref_cbw, ref_tile; // the refinement's column-block width / LDS pixel tile (its scratch is this kernel's dynamic LDS)
+    int ref_cbw;         // the refinement's column-block width (its scratch — row-pass block AND pixel tile — is this kernel's dynamic LDS)
 };
 
 constexpr int FUSED_NT = 1024, FUSED_PMAX = 8, FUSED_U = 8;
@@ -324,9 +324,9 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
             c.T64 = fg.T64;
             c.T = g.ex.T;
             c.cbw = fg.ref_cbw;
-            c.use_tile = fg.ref_tile;
+            c.use_tile = 1;
             c.lds = smem;
-            const int idx = refine_window(NT, g, frame, g1, g2, s_max, c, [](int, int) { return true; });
+            const int idx = refine_window<true>(NT, g, frame, g1, g2, s_max, c, [](int, int) { return true; });
             if (tid == 0) {
                 const int x = idx / g.n1, y = idx - x * g.n1;
                 const int i = min(max(g1 - g.r1 + y, 1), g.fh);

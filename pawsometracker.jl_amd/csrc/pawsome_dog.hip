@@ -296,10 +296,10 @@ void setup_refine_geometry(pdog_tracker *t)
     t->ref_tile = refine_lds_bytes(t->n1, t->L, t->ref_cbw, true) <= 100 * 1024; // (one workgroup per CU beyond 80 KB: fine for a kernel whose blocks mostly exit at once)
     // inside the fused kernel the scratch is that kernel's own LDS (tile + RT, free by then): the widest block that fits it
     t->fused_ref_cbw = 1;
-    t->fused_ref_tile = refine_lds_bytes(t->n1, t->L, 1, true) <= kMaxLds - 1024; // tiny windows: the scratch is larger than tile + RT
+    t->fused_ref_tile = true; // always: a window whose tile + RT fit in LDS as floats has room for its pixels as bytes
     const size_t have = fused_lds_bytes(t->n1, t->n2, t->L);
     for (int cbw = std::min(8, t->n2); cbw >= 1; --cbw)
-        if (refine_lds_bytes(t->n1, t->L, cbw, true) <= have) { t->fused_ref_cbw = cbw; t->fused_ref_tile = true; break; }
+        if (refine_lds_bytes(t->n1, t->L, cbw, true) <= have) { t->fused_ref_cbw = cbw; break; }
 }
 // dynamic LDS of the fused kernel: its tile + RT, or the scratch of the refinement it may run in the same memory
 size_t fused_total_lds(const pdog_tracker *t)
@@ -541,7 +541,6 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     fg.dir = t->darker ? -1.0 : 1.0;
     fg.T64 = t->exact_T64;
     fg.ref_cbw = t->fused_ref_cbw;
-    fg.ref_tile = t->fused_ref_tile ? 1 : 0;
     g.ex = exact_ctl(t);
     const size_t lds = fused_total_lds(t);
     typedef fused_fn_t fused_fn;
