@@ -350,6 +350,7 @@ def main():
         pt.gather_positions(out, n_total)   # RCCL sets up its point-to-point channels on first use: not part of any timed step
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
+    refined0 = bt.exact_stats()[2]
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -382,6 +383,10 @@ def main():
         sharding = (f"frames x{world}, one process per GPU, gather int32[n,2] to rank 0" + ("" if backend == "nccl" else f" ({backend} rehearsal)")) \
             if world > 1 else "single GPU"
         res = result_line(args, desc, world, dt, kern_ms, batch, info, bt.kernel_for_batch(batch), fh, fw, tw, sharding)
+        on, thr, refined1 = bt.exact_stats()
+        res["exact"] = {"on": on, "threshold_2delta": thr, "refined_windows_per_step": (refined1 - refined0) / args.steps,
+                        "note": "windows whose two best FP32 responses lay within 2*delta and were re-decided in the reference's Float64 "
+                                "arithmetic inside the timed region (rank 0's shard)"}
         if world == 1 and not args.no_cpu:
             ns = min(256, batch)
             cb = cpu_baseline(frames[:ns].cpu().numpy(), guesses_h[:ns], fill, tw, radii)

@@ -80,12 +80,10 @@ __device__ __forceinline__ void roll_row_pass(f2 (&acc)[ROLL_P], const float *a,
 {
     constexpr int P = ROLL_P, H = L / 2, U = 4, NP = P / 2;
     constexpr int W = 2 * (NP - 1) + U; // pairs per window: n = base + (2*op + u)
-    // Pairs at odd n come through a second, laundered pointer: seen as the same memory the compiler loads every
-    // float once and assembles the odd pairs with v_pk_mov_b32 / v_mov_b32 (≈50 VALU slots per sub-chunk); the LDS
-    // pipe has room for the extra ds_read2_b32, the VALU has not.
-    const float *ao = a;
-    asm volatile("" : "+v"(ao));
-    auto pair_at = [&](int n) { return (n & 1) ? f2{ao[n], ao[n + 1]} : f2{a[n], a[n + 1]}; };
+    // (Loading the pairs at odd n through a second, laundered pointer — so that the compiler reloads them instead of
+    // assembling them with ≈50 v_pk_mov_b32 / v_mov_b32 per sub-chunk — was measured 40 % SLOWER: the row pass is as
+    // close to the LDS pipe's limit as to the VALU's.)
+    auto pair_at = [&](int n) { return f2{a[n], a[n + 1]}; };
     f2 lo[W], hi[W];
 #pragma unroll
     for (int j = 0; j < W; ++j) {

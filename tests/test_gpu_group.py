@@ -142,3 +142,56 @@ def test_alternating_torch_streams_keep_the_scratch_ordered(pt, oracle):
             assert torch.equal(o, a_ref if k % 2 == 0 else b_ref), (tw, k)
         assert np.array_equal(a_ref[:16].cpu().numpy(), ref)
         bt.close()
+
+
+def test_device_guess_out_of_range_is_reported_by_sync(pt, oracle):
+    """Device-resident guesses cannot be checked before the launch; where the reference raises BoundsError
+    (guess outside [-l÷2, sz + l÷2 + 1], src/PawsomeTracker.jl:45-46) the kernels raise a flag that pdog_sync reports
+    as PDOG_E_RANGE — once: the flag is cleared by the call that reports it.  Every kernel family."""
+    import torch
+    from oracle import synth
+    tw, ws, fh, fw = 25, (45, 45), 120, 160
+    radii = (22, 22)
+    hw = oracle.kernel_len(oracle.sigma(tw)) // 2
+    frames, guesses, _ = synth.make_batch(6, fh, fw, tw, radii, True, seed=3, noise=2)
+    fill = oracle.mode_u8(frames[0])
+    d_f = torch.from_numpy(frames).cuda()
+    edge = guesses.copy()
+    edge[0] = (-hw, fw + hw + 1)              # the outermost legal guess
+    bad = guesses.copy()
+    bad[3] = (fh + hw + 2, 10)                # one row too far
+    for variant in (-1, 300, 100, 200, 13):
+        bt = pt.BatchTracker(fh, fw, tw, ws, True, fill)
+        if variant >= 0:
+            bt.set_variant(variant)
+        bt.detect(d_f, torch.from_numpy(edge).cuda())
+        bt.sync()                              # legal: no error
+        out = bt.detect(d_f, torch.from_numpy(bad).cuda())
+        with pytest.raises(pt.PdogError) as e:
+            bt.sync()
+        assert e.value.code == pt._lib.PDOG_E_RANGE and "BoundsError" in str(e.value), variant
+        bt.sync()                              # reported once
+        ref = oracle.detect_batch(frames[:3], fill, oracle.dog_kernel(oracle.sigma(tw), True), radii, bad[:3])
+        assert np.array_equal(out.cpu().numpy()[:3], ref)      # the in-range windows of that batch are still right
+        # the serial chain checks its start guess the same way
+        bt.detect_chains(d_f[None, :3].contiguous(), torch.tensor([[fh + hw + 2, 5]], dtype=torch.int32).cuda())
+        with pytest.raises(pt.PdogError):
+            bt.sync()
+        bt.close()
+
+
+def test_switches_are_read_once_at_create(pt, oracle, monkeypatch):
+    """The PDOG_* environment switches are sampled when a tracker is created, never on the launch path: flipping one
+    afterwards does not change a live tracker, a new tracker sees it."""
+    from oracle import synth
+    frames, guesses, _ = synth.make_batch(1, 120, 160, 25, (22, 22), True, seed=4, noise=2)
+    monkeypatch.delenv("PDOG_NO_EXACT", raising=False)
+    t1 = pt.Tracker(frames[0], 25, (45, 45), True)
+    assert t1.exact_stats()[0] is True
+    monkeypatch.setenv("PDOG_NO_EXACT", "1")
+    assert t1.exact_stats()[0] is True
+    t2 = pt.Tracker(frames[0], 25, (45, 45), True)
+    assert t2.exact_stats()[0] is False
+    g = (int(guesses[0, 0]), int(guesses[0, 1]))
+    assert t1(g) == t2(g)
+    t1.close(); t2.close()
