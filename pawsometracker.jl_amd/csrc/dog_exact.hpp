@@ -192,14 +192,26 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
         for (int x0 = 0; x0 < g.n2; x0 += c.cbw) {
             const int ncol = min(c.cbw, g.n2 - x0);
             if (!may(x0, x0 + ncol)) continue;
-            const int tp = refine_tile_pitch(ncol, L), tw = ncol + L - 1;
-            if constexpr (TILE) {
-                for (int e = tid; e < NA * tw; e += NT) {
-                    const int a = e / tw, cc = e - a * tw;
-                    const int gi = ti0 + a, gj = wj0 + x0 + cc;
-                    int px = g.fill; // PaddedView, :48
-                    if (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) px = frame[(long long)gi * g.row_stride + gj];
-                    tile[a * tp + cc] = (uint8_t)px;
+            const int tp = refine_tile_pitch(ncol, L);
+            if constexpr (TILE) { // a dword (4 pixels) per item, several in flight per thread; PaddedView fill (:48) outside the frame
+                const int tq = tp >> 2;
+                const uint32_t fill4 = (uint32_t)g.fill * 0x01010101u;
+#pragma unroll 4
+                for (int e = tid; e < NA * tq; e += NT) {
+                    const int a = e / tq, q = e - a * tq;
+                    const int gi = ti0 + a, gj = wj0 + x0 + 4 * q;
+                    uint32_t w = fill4;
+                    if (gi >= 0 && gi < g.fh) {
+                        const uint8_t *src = frame + (long long)gi * g.row_stride;
+                        if (gj >= 0 && gj + 4 <= g.fw) {
+                            __builtin_memcpy(&w, src + gj, 4);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (gj + i >= 0 && gj + i < g.fw) w = (w & ~(0xffu << (8 * i))) | ((uint32_t)src[gj + i] << (8 * i));
+                        }
+                    }
+                    *reinterpret_cast<uint32_t *>(tile + a * tp + 4 * q) = w;
                 }
                 __syncthreads();
             }

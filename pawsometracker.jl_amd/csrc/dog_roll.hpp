@@ -167,19 +167,26 @@ __host__ __device__ constexpr int roll_col_table_len(int L) { return roll_col_bl
 // slots whose outputs do not exist (20 % of the column pass's FMAs over the first and last l−1 rows).  Up there the
 // phase equals the sub-chunk number, so the shortened bodies are static instances with no branch inside.
 __host__ __device__ constexpr int roll_prologue_blocks(int sc) { return 2 * sc + 2; }
+// Bottom edge: rows a = 8 sc … need tap blocks qb ≥ qlo(sc) = 2 sc − c0, c0 = (n1 + 2) ÷ 4.  With the phase sc mod NBODY
+// the pair (phase, qlo) of every epilogue sub-chunk is fixed by c0 mod 2·NBODY: the window's height class.
+__host__ __device__ constexpr int roll_epi_c0(int n1) { return (n1 + 2) / 4; }
+__host__ __device__ constexpr int roll_epi_class(int n1, int L) { return roll_epi_c0(n1) % (2 * (roll_slots(L) / ROLL_CH)); }
 __host__ __device__ constexpr int roll_prologue_len(int L) { return (roll_col_blocks(L) - 2 + 1) / 2; } // sub-chunks with fewer blocks than the full body
-template <int L, int SC, int QHI = roll_col_blocks(L)>
+// QLO > 0: an EPILOGUE body, blocks QLO … only: the last input rows a > n1−1 have no output below row n1−1 to feed,
+// rows a … a+7 only need taps t ≥ a − (n1−1).  Down there sub-chunk and phase are tied through the window height, so
+// these bodies exist per HEIGHT CLASS (roll_epi_class) — instances for the common window sizes only.
+template <int L, int SC, int QHI = roll_col_blocks(L), int QLO = 0>
 __device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], const f2 (&rv)[ROLL_CH], tap_ptr table)
 {
     constexpr int S = roll_slots(L), CH = ROLL_CH, QB = ROLL_QB, NQB = QHI;
-    static_assert(QHI >= 1 && QHI <= roll_col_blocks(L), "tap-block bound out of range");
+    static_assert(QHI >= 1 && QHI <= roll_col_blocks(L) && QLO >= 0 && QLO < QHI, "tap-block bounds out of range");
     static_assert(S % 2 == 0 && (CH * SC) % 2 == 0, "pairing needs even slot counts");
     f2 tn[4 * QB];
     tap_ptr tb = pin_taps(table);
 #pragma unroll
-    for (int j = 0; j < 4 * QB; ++j) tn[j] = tb[j];
+    for (int j = 0; j < 4 * QB; ++j) tn[j] = tb[QLO * 4 * QB + j];
 #pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) {
+    for (int qb = QLO; qb < NQB; ++qb) {
         f2 t[4 * QB];
 #pragma unroll
         for (int j = 0; j < 4 * QB; ++j) t[j] = tn[j];
@@ -229,7 +236,8 @@ __device__ __forceinline__ void roll_col_body(f2 (&acc2)[roll_slots(L) / 2], con
 // conversion/LDS writes, 8 = no global loads.  ABL != 0 gives wrong results by design.
 // One strip of one window, executed by ONE wave with wave-private LDS at `smem`: everything from the DC
 // level to the wave-level peak reduction.  (best, best_idx) are valid in lane 0 on return.
-template <int LT, bool RESP, int ABL>
+// EPI ≥ 0: the instance for windows of height class EPI (roll_epi_class): statically shortened epilogue bodies too.
+template <int LT, bool RESP, int ABL, int EPI = -1>
 __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restrict__ taps_row, const f2 *__restrict__ taps_col,
                                            unsigned char *smem, const uint8_t *__restrict__ frame, int g1, int g2, int s,
                                            int b, int logical, Peak &peak_out, unsigned long long &mask_out)
@@ -350,9 +358,10 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
 #pragma unroll
         for (int i = 0; i < CH; ++i) rv[i] = Rb[i * ROLL_PR + lane];
         const int phase = sc % NBODY;
-        auto emit = [&](auto SCc, auto QHIc) {
-            constexpr int SC = decltype(SCc)::value, QHI = decltype(QHIc)::value;
-            if (!(ABL & 1)) roll_col_body<L, SC, QHI>(acc2, rv, tcol);
+        const int sc_e = roll_epi_c0(g.n1) / 2 + 1; // first sub-chunk whose rows need no tap of the first block(s)
+        auto emit = [&](auto SCc, auto QHIc, auto QLOc) {
+            constexpr int SC = decltype(SCc)::value, QHI = decltype(QHIc)::value, QLO = decltype(QLOc)::value;
+            if (!(ABL & 1)) roll_col_body<L, SC, QHI, QLO>(acc2, rv, tcol);
             // outputs y = a − (l−1) for the 8 rows of this sub-chunk are complete.  A lane owns ONE
             // column and meets its rows in increasing y (= increasing column-major index), so a strict
             // '>' keeps the first maximum of the lane (findmax, :59); ties between lanes and strips
@@ -375,12 +384,29 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
             // (no reset: the emitted slots are reused S rows later, and their first term is a multiply, see roll_col_body)
         };
         static_assert(NBODY <= 16 && NPRO < NBODY && NPRO <= 16, "extend the phase switches");
-#define PDOG_FULL(k) case k: emit(std::integral_constant<int, (k) % NBODY>{}, std::integral_constant<int, roll_col_blocks(L)>{}); break;
+#define PDOG_FULL(k) case k: emit(std::integral_constant<int, (k) % NBODY>{}, std::integral_constant<int, roll_col_blocks(L)>{}, std::integral_constant<int, 0>{}); break;
 #define PDOG_PRO(k)                                                                                                   \
     case k:                                                                                                           \
-        if constexpr ((k) < NPRO) emit(std::integral_constant<int, (k) % NBODY>{}, std::integral_constant<int, ((k) < NPRO ? roll_prologue_blocks(k) : 1)>{}); \
+        if constexpr ((k) < NPRO) emit(std::integral_constant<int, (k) % NBODY>{}, std::integral_constant<int, ((k) < NPRO ? roll_prologue_blocks(k) : 1)>{}, std::integral_constant<int, 0>{}); \
         break;
-        if (sc < NPRO) { // the first rows: shortened bodies (sub-chunk = phase)
+        if (EPI >= 0 && sc >= sc_e) { // the last rows of a window of this height class: shortened bodies
+            if constexpr (EPI >= 0) {
+                // first epilogue sub-chunk sc_e = c0 ÷ 2 + 1: phase (EPI ÷ 2 + 1) mod NBODY (even class) …, qlo = 2 − (c0 mod 2), +2 per sub-chunk
+                constexpr int PH0 = (EPI / 2 + 1) % NBODY, Q0 = 2 - (EPI & 1);
+#define PDOG_EPI(e)                                                                                                          \
+    case e:                                                                                                                  \
+        if constexpr (Q0 + 2 * (e) < roll_col_blocks(L))                                                                     \
+            emit(std::integral_constant<int, (PH0 + (e)) % NBODY>{}, std::integral_constant<int, roll_col_blocks(L)>{},      \
+                 std::integral_constant<int, (Q0 + 2 * (e) < roll_col_blocks(L) ? Q0 + 2 * (e) : 0)>{});                     \
+        break;
+                switch (sc - sc_e) {
+                    PDOG_EPI(0) PDOG_EPI(1) PDOG_EPI(2) PDOG_EPI(3) PDOG_EPI(4) PDOG_EPI(5) PDOG_EPI(6) PDOG_EPI(7)
+                    PDOG_EPI(8) PDOG_EPI(9) PDOG_EPI(10) PDOG_EPI(11) PDOG_EPI(12) PDOG_EPI(13)
+                default: break;
+                }
+#undef PDOG_EPI
+            }
+        } else if (sc < NPRO) { // the first rows: shortened bodies (sub-chunk = phase)
             switch (sc) {
                 PDOG_PRO(0) PDOG_PRO(1) PDOG_PRO(2) PDOG_PRO(3) PDOG_PRO(4) PDOG_PRO(5) PDOG_PRO(6) PDOG_PRO(7)
                 PDOG_PRO(8) PDOG_PRO(9) PDOG_PRO(10) PDOG_PRO(11) PDOG_PRO(12) PDOG_PRO(13) PDOG_PRO(14) PDOG_PRO(15)
@@ -390,7 +416,7 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
             switch (phase) {
                 PDOG_FULL(0) PDOG_FULL(1) PDOG_FULL(2) PDOG_FULL(3) PDOG_FULL(4) PDOG_FULL(5) PDOG_FULL(6) PDOG_FULL(7)
                 PDOG_FULL(8) PDOG_FULL(9) PDOG_FULL(10) PDOG_FULL(11) PDOG_FULL(12) PDOG_FULL(13) PDOG_FULL(14)
-            default: emit(std::integral_constant<int, 15 % NBODY>{}, std::integral_constant<int, roll_col_blocks(L)>{}); break;
+            default: emit(std::integral_constant<int, 15 % NBODY>{}, std::integral_constant<int, roll_col_blocks(L)>{}, std::integral_constant<int, 0>{}); break;
             }
         }
 #undef PDOG_FULL
@@ -445,7 +471,7 @@ __device__ __attribute__((noinline)) void roll_strip_call(const LaunchGeo *gp, c
 }
 constexpr int ROLL_CALL_LMIN = 101; // batch kernels from this length on run the out-of-line strip too
 
-template <int LT, bool RESP, int ABL = 0>
+template <int LT, bool RESP, int ABL = 0, int EPI = -1>
 __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, const f2 *__restrict__ taps_row,
                                                          const f2 *__restrict__ taps_col)
 {
@@ -464,7 +490,7 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
     if constexpr (LT >= ROLL_CALL_LMIN && !RESP && ABL == 0)
         roll_strip_call<LT>(&g, taps_row, taps_col, smem, frame, g1, g2, s, b, &pk, &mask);
     else
-        roll_strip<LT, RESP, ABL>(g, taps_row, taps_col, smem, frame, g1, g2, s, b, logical, pk, mask);
+        roll_strip<LT, RESP, ABL, EPI>(g, taps_row, taps_col, smem, frame, g1, g2, s, b, logical, pk, mask);
     if (threadIdx.x == 0) {
         g.part_mask[b * g.nslots + s] = mask;
         g.part_val[b * g.nslots + s] = pk.best;

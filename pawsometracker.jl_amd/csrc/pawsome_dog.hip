@@ -37,6 +37,8 @@ namespace pdog {
     extern template __global__ void dog_chain_kernel<LT>(const ChainGeo, const f2 *, const f2 *);
 #include "roll_lengths.def"
 #undef PDOG_ROLL_L
+extern template __global__ void dog_roll_kernel<65, false, 0, 10>(const LaunchGeo, const f2 *, const f2 *);
+extern template __global__ void dog_roll_kernel<65, false, 0, 2>(const LaunchGeo, const f2 *, const f2 *);
 } // namespace pdog
 
 namespace {
@@ -709,7 +711,13 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         (void)raise_lds_limit((const void *)(d_out_resp ? v.fn_resp : v.fn), lds_bytes);
     }
 #endif
-    hipLaunchKernelGGL(d_out_resp ? v.fn_resp : v.fn, dim3(grid), dim3(v.NT), lds_bytes, t->stream, g,
+    kernel_fn fn = d_out_resp ? v.fn_resp : v.fn;
+    if (!d_out_resp && v.roll && v.LT == 65 && v.id == 100) { // instances with statically shortened epilogue bodies for the common window heights
+        const int cls = roll_epi_class(t->n1, 65);
+        if (cls == 10) fn = (kernel_fn)dog_roll_kernel<65, false, 0, 10>;
+        else if (cls == 2) fn = (kernel_fn)dog_roll_kernel<65, false, 0, 2>;
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(v.NT), lds_bytes, t->stream, g,
                        (const f2 *)t->d_taps_row, (const f2 *)(v.roll ? t->d_taps_roll : t->d_taps_col));
     HIP_TRY(hipGetLastError());
     if (t->nthin) HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0)); // join before the strip combine
