@@ -174,7 +174,7 @@ def test_device_guess_out_of_range_is_reported_by_sync(pt, oracle):
         ref = oracle.detect_batch(frames[:3], fill, oracle.dog_kernel(oracle.sigma(tw), True), radii, bad[:3])
         assert np.array_equal(out.cpu().numpy()[:3], ref)      # the in-range windows of that batch are still right
         # the serial chain checks its start guess the same way
-        bt.detect_chains(d_f[None, :3].contiguous(), torch.tensor([[fh + hw + 2, 5]], dtype=torch.int32).cuda())
+        bt.detect_chains(d_f[:3].clone().unsqueeze(0), torch.tensor([[fh + hw + 2, 5]], dtype=torch.int32).cuda())
         with pytest.raises(pt.PdogError):
             bt.sync()
         bt.close()
