@@ -193,25 +193,36 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
             const int ncol = min(c.cbw, g.n2 - x0);
             if (!may(x0, x0 + ncol)) continue;
             const int tp = refine_tile_pitch(ncol, L);
-            if constexpr (TILE) { // a dword (4 pixels) per item, several in flight per thread; PaddedView fill (:48) outside the frame
+            if constexpr (TILE) {
+                // A dword (4 pixels) per item.  The load is unconditional at an address clamped into the frame (a clamped
+                // dword still holds every in-frame byte its item needs, at a shifted position) and the PaddedView fill (:48)
+                // is selected afterwards: no branch between two loads, so a thread's loads are all in flight together
+                // (one memory round trip per 4 items instead of one per item: the tile is cold by now).
                 const int tq = tp >> 2;
-                const uint32_t fill4 = (uint32_t)g.fill * 0x01010101u;
+                if (g.fw >= 4) {
 #pragma unroll 4
-                for (int e = tid; e < NA * tq; e += NT) {
-                    const int a = e / tq, q = e - a * tq;
-                    const int gi = ti0 + a, gj = wj0 + x0 + 4 * q;
-                    uint32_t w = fill4;
-                    if (gi >= 0 && gi < g.fh) {
-                        const uint8_t *src = frame + (long long)gi * g.row_stride;
-                        if (gj >= 0 && gj + 4 <= g.fw) {
-                            __builtin_memcpy(&w, src + gj, 4);
-                        } else {
+                    for (int e = tid; e < NA * tq; e += NT) {
+                        const int a = e / tq, q = e - a * tq;
+                        const int gi = ti0 + a, gj = wj0 + x0 + 4 * q;
+                        const int gjc = min(max(gj, 0), g.fw - 4);
+                        uint32_t w;
+                        __builtin_memcpy(&w, frame + (long long)min(max(gi, 0), g.fh - 1) * g.row_stride + gjc, 4);
+                        const bool rowok = gi >= 0 && gi < g.fh;
+                        uint32_t o = 0;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                if (gj + i >= 0 && gj + i < g.fw) w = (w & ~(0xffu << (8 * i))) | ((uint32_t)src[gj + i] << (8 * i));
+                        for (int i = 0; i < 4; ++i) {
+                            const int gjj = gj + i;
+                            const uint32_t px = (rowok && gjj >= 0 && gjj < g.fw) ? ((w >> (8 * ((gjj - gjc) & 3))) & 0xffu) : (uint32_t)g.fill;
+                            o |= px << (8 * i);
                         }
+                        *reinterpret_cast<uint32_t *>(tile + a * tp + 4 * q) = o;
                     }
-                    *reinterpret_cast<uint32_t *>(tile + a * tp + 4 * q) = w;
+                } else {
+                    for (int e = tid; e < NA * tp; e += NT) {
+                        const int a = e / tp, cc = e - a * tp;
+                        const int gi = ti0 + a, gj = wj0 + x0 + cc;
+                        tile[e] = (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) ? frame[(long long)gi * g.row_stride + gj] : (uint8_t)g.fill;
+                    }
                 }
                 __syncthreads();
             }
@@ -252,9 +263,13 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                     f2 acc[8];
 #pragma unroll
                     for (int x = 0; x < 8; ++x) acc[x] = f2{0.f, 0.f};
+                    int nx[24];
+                    row_chunk(a, 0, nx);
                     for (int k0 = 0; k0 < L; k0 += 16) {
                         int px[24];
-                        row_chunk(a, k0, px);
+#pragma unroll
+                        for (int i = 0; i < 24; ++i) px[i] = nx[i];
+                        if (k0 + 16 < L) row_chunk(a, k0 + 16, nx); // the next stretch is requested before this one is consumed
 #pragma unroll
                         for (int u = 0; u < 16; ++u) {
                             if (k0 + u < L) {
@@ -317,9 +332,13 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                         double sp[8], sm[8];
 #pragma unroll
                         for (int x = 0; x < 8; ++x) sp[x] = sm[x] = 0.0;
+                        int nx[24];
+                        row_chunk(a, 0, nx);
                         for (int k0 = 0; k0 < L; k0 += 16) {
                             int px[24];
-                            row_chunk(a, k0, px);
+#pragma unroll
+                            for (int i = 0; i < 24; ++i) px[i] = nx[i];
+                            if (k0 + 16 < L) row_chunk(a, k0 + 16, nx);
                             double v[24];
 #pragma unroll
                             for (int i = 0; i < 24; ++i) v[i] = lut[px[i]];
