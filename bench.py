@@ -385,6 +385,7 @@ def main():
         res = result_line(args, desc, world, dt, kern_ms, batch, info, bt.kernel_for_batch(batch), fh, fw, tw, sharding)
         on, thr, refined1 = bt.exact_stats()
         res["exact"] = {"on": on, "threshold_2delta": thr, "refined_windows_per_step": (refined1 - refined0) / args.steps,
+                        "since_create": dict(zip(("windows", "column_blocks", "candidates", "sequential_chains"), bt.exact_detail())),
                         "note": "windows whose two best FP32 responses lay within 2*delta and were re-decided in the reference's Float64 "
                                 "arithmetic inside the timed region (rank 0's shard)"}
         if world == 1 and not args.no_cpu:

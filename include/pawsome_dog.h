@@ -129,6 +129,10 @@ int pdog_sync(pdog_tracker *t);
  * since the tracker was created (any of the out pointers may be NULL; reading the count drains the stream). */
 int pdog_set_exact(pdog_tracker *t, int on);
 int pdog_get_exact(pdog_tracker *t, int *out_on, double *out_threshold, uint64_t *out_refined);
+/* Where the re-evaluation's work went since the tracker was created: out[0] windows refined, out[1] column blocks
+ * rescanned in FP32, out[2] candidates evaluated in separable Float64, out[3] sequential dense Float64 chains run
+ * (0 for a window whose separable stage left a single survivor).  Drains the stream. */
+int pdog_get_exact_detail(pdog_tracker *t, uint64_t out[4]);
 
 /* ---- the functor, src/PawsomeTracker.jl:55-62, n independent applications ----
  * All pointers are DEVICE pointers.

@@ -21,7 +21,7 @@ SYMBOLS = (
     "pdog_alloc_host", "pdog_free_host", "pdog_detect_chain_progress", "pdog_get_stream",
     "pdog_group_create", "pdog_group_destroy", "pdog_group_size", "pdog_group_tracker", "pdog_group_shard",
     "pdog_group_detect_batch", "pdog_group_sync", "pdog_shard_range", "pdog_shard_owner",
-    "pdog_set_exact", "pdog_get_exact", "pdog_dense_kernel",
+    "pdog_set_exact", "pdog_get_exact", "pdog_get_exact_detail", "pdog_dense_kernel",
 )
 
 
@@ -128,6 +128,7 @@ def lib():
     if hasattr(L, "pdog_set_exact"):
         L.pdog_set_exact.restype = i; L.pdog_set_exact.argtypes = [p, i]
         L.pdog_get_exact.restype = i; L.pdog_get_exact.argtypes = [p, C.POINTER(i), C.POINTER(d), C.POINTER(C.c_uint64)]
+        L.pdog_get_exact_detail.restype = i; L.pdog_get_exact_detail.argtypes = [p, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 

@@ -39,6 +39,12 @@ class BatchTracker:
         _lib.check(_lib.lib().pdog_get_exact(self._h, C.byref(on), C.byref(thr), C.byref(n)))
         return bool(on.value), thr.value, int(n.value)
 
+    def exact_detail(self):
+        """(windows refined, column blocks rescanned, candidates, sequential chains) — pdog_get_exact_detail."""
+        out = (C.c_uint64 * 4)()
+        _lib.check(_lib.lib().pdog_get_exact_detail(self._h, out))
+        return tuple(int(v) for v in out)
+
     def kernel_for_batch(self, n):
         """Variant id of the kernel family a batch of n windows runs on (300 fused, 200 two-pass, else info().variant)."""
         o = C.c_int()

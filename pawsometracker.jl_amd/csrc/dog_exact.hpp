@@ -192,6 +192,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
         for (int x0 = 0; x0 < g.n2; x0 += c.cbw) {
             const int ncol = min(c.cbw, g.n2 - x0);
             if (!may(x0, x0 + ncol)) continue;
+            if (tid == 0 && !direct) atomicAdd(g.ex.stat + 1, 1ull); // column blocks rescanned (diagnostics)
             const int tp = refine_tile_pitch(ncol, L);
             if constexpr (TILE) {
                 // A dword (4 pixels) per item.  The load is unconditional at an address clamped into the frame (a clamped
@@ -401,6 +402,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
             __syncthreads();
         }
         const int ns = cnt[2];
+        if (tid == 0) { atomicAdd(g.ex.stat + 2, (unsigned long long)n); atomicAdd(g.ex.stat + 3, (unsigned long long)(ns == 1 ? 0 : ns)); }
         if (ns == 1) {
             if (tid == 0) cnt[3] = cand_lin[0];
         } else {
@@ -492,18 +494,35 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
     c.cbw = fg.cbw;
     c.use_tile = fg.use_tile;
     c.lds = smem;
-    const float thr = s_max - g.ex.T;
-    const float *pv = g.part_val + (long long)b * g.nslots;
-    const unsigned long long *pm = g.part_mask + (long long)b * g.nslots;
-    auto may = [&](int x0, int x1) {
-        bool any = false;
-        for (int s = 0; s < g.nslots; ++s) { // a handful of slots; uniform
-            int lo, hi;
-            if (s < fg.nmain) { lo = min(s * fg.slot_w, fg.slot_last); hi = lo + fg.slot_w; }
-            else { lo = fg.thin_x0 + (s - fg.nmain); hi = lo + 1; }
-            if (lo < x1 && hi > x0 && pv[s] >= thr && (!fg.use_mask || s >= fg.nmain || (pm[s] & column_bits(x0 - lo, x1 - lo)))) any = true;
+    // the slots' maxima and column masks once, into LDS: `may` is asked once per column block
+    constexpr int SLOT_CAP = 128;
+    __shared__ float s_pv[SLOT_CAP];
+    __shared__ unsigned long long s_pm[SLOT_CAP];
+    const bool slots_ok = g.nslots <= SLOT_CAP;
+    if (slots_ok)
+        for (int s = tid; s < g.nslots; s += NT) {
+            s_pv[s] = g.part_val[(long long)b * g.nslots + s];
+            s_pm[s] = fg.use_mask ? g.part_mask[(long long)b * g.nslots + s] : ~0ull;
         }
-        return any;
+    __syncthreads();
+    const float thr = s_max - g.ex.T;
+    auto may = [&](int x0, int x1) {
+        if (!slots_ok) return true;
+        // main slots: slot s covers [min(s·slot_w, slot_last), + slot_w); only those that can intersect [x0, x1) are looked at
+        const int s_lo = max(0, x0 / fg.slot_w - 1), s_hi = min(fg.nmain, x1 / fg.slot_w + 2);
+        for (int s = s_lo; s < s_hi; ++s) {
+            const int lo = min(s * fg.slot_w, fg.slot_last), hi = lo + fg.slot_w;
+            if (lo < x1 && hi > x0 && s_pv[s] >= thr && (s >= fg.nmain || (s_pm[s] & column_bits(x0 - lo, x1 - lo)) || fg.slot_w != 64)) return true;
+        }
+        if (fg.slot_last < (1 << 29) && fg.nmain > 0) { // the roll kernel's last strip, shifted left: overlaps its predecessors
+            const int s = fg.nmain - 1, lo = fg.slot_last, hi = lo + fg.slot_w;
+            if (lo < x1 && hi > x0 && s_pv[s] >= thr && (s_pm[s] & column_bits(x0 - lo, x1 - lo))) return true;
+        }
+        for (int s = fg.nmain; s < g.nslots; ++s) { // thin columns
+            const int lo = fg.thin_x0 + (s - fg.nmain);
+            if (lo < x1 && lo >= x0 && s_pv[s] >= thr) return true;
+        }
+        return false;
     };
     const int idx = fg.use_tile ? refine_window<true>(NT, g, frame, g1, g2, s_max, c, may) : refine_window<false>(NT, g, frame, g1, g2, s_max, c, may);
     if (tid == 0) {

@@ -74,7 +74,7 @@ __device__ __forceinline__ void peak_wave_reduce(Peak &p, int width = 64)
 // Exact mode (dog_exact.hpp): a window whose two best FP32 responses lie within T = 2δ of each other is re-decided
 // by a Float64 re-evaluation of its near-maximal pixels.
 struct ExactCtl {
-    unsigned long long *stat; // [1] windows re-evaluated since the tracker was created (diagnostics)
+    unsigned long long *stat; // [4] since the tracker was created: windows refined, column blocks rescanned, candidates, sequential chains run (diagnostics)
     int *range_err;           // host-coherent word: set when a guess lies where the reference raises BoundsError (:45-46)
     float T;                  // 2δ
 };

@@ -105,6 +105,12 @@ class Tracker:
         _lib.check(_lib.lib().pdog_get_exact(self._h, C.byref(on), C.byref(thr), C.byref(n)))
         return bool(on.value), thr.value, int(n.value)
 
+    def exact_detail(self):
+        """(windows refined, column blocks rescanned, candidates, sequential chains) — pdog_get_exact_detail."""
+        out = (C.c_uint64 * 4)()
+        _lib.check(_lib.lib().pdog_get_exact_detail(self._h, out))
+        return tuple(int(v) for v in out)
+
     def set_variant(self, variant):
         _lib.check(_lib.lib().pdog_set_variant(self._h, int(variant)))
 
