@@ -256,7 +256,15 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                     const int a = e / ncol, x = e - a * ncol;
                     const uint8_t *src = tile + a * tp + x;
                     f2 acc = f2{0.f, 0.f};
-                    for (int k = 0; k < L; ++k) acc = fma_bcast((float)((int)src[k] - dc), c.trow[k], acc);
+                    int k = 0;
+                    for (; k + 8 <= L; k += 8) { // 8 pixel reads and 8 taps requested together; only the FMAs form a chain
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = (float)((int)src[k + u] - dc);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc = fma_bcast(v[u], c.trow[k + u], acc);
+                    }
+                    for (; k < L; ++k) acc = fma_bcast((float)((int)src[k] - dc), c.trow[k], acc);
                     R32[e] = acc;
                 }
             } else {
@@ -293,7 +301,19 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
             for (int e = tid; e < g.n1 * ncol; e += NT) {
                 const int x = e / g.n1, y = e - x * g.n1;
                 float acc = 0.f;
-                for (int t = 0; t < L; ++t) {
+                int t = 0;
+                for (; t + 8 <= L; t += 8) {
+                    f2 r[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) r[u] = R32[(y + t + u) * ncol + x];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const f2 w = c.tcol[t + u];
+                        acc = __builtin_fmaf(r[u].x, w.x, acc);
+                        acc = __builtin_fmaf(r[u].y, w.y, acc);
+                    }
+                }
+                for (; t < L; ++t) {
                     const f2 r = R32[(y + t) * ncol + x];
                     const f2 w = c.tcol[t];
                     acc = __builtin_fmaf(r.x, w.x, acc);
@@ -320,7 +340,18 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                         const int a = e / ncol, x = e - a * ncol;
                         const uint8_t *src = tile + a * tp + x;
                         double sp = 0.0, sm = 0.0;
-                        for (int k = 0; k < L; ++k) {
+                        int k = 0;
+                        for (; k + 8 <= L; k += 8) {
+                            double v[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) v[u] = lut[src[k + u]];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                sp = __builtin_fma(c.g64[k + u], v[u], sp);
+                                sm = __builtin_fma(c.g64[L + k + u], v[u], sm);
+                            }
+                        }
+                        for (; k < L; ++k) {
                             const double v = lut[src[k]];
                             sp = __builtin_fma(c.g64[k], v, sp);
                             sm = __builtin_fma(c.g64[L + k], v, sm);
@@ -364,7 +395,15 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                     const int lin = cand_lin[k];
                     const int xw = lin / g.n1, y = lin - xw * g.n1, x = xw - x0;
                     double sp = 0.0, sm = 0.0;
-                    for (int t = 0; t < L; ++t) {
+                    int t = 0;
+                    for (; t + 8 <= L; t += 8) {
+                        double rp[8], rm[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { rp[u] = R64[2 * ((y + t + u) * ncol + x)]; rm[u] = R64[2 * ((y + t + u) * ncol + x) + 1]; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { sp = __builtin_fma(c.g64[t + u], rp[u], sp); sm = __builtin_fma(c.g64[L + t + u], rm[u], sm); }
+                    }
+                    for (; t < L; ++t) {
                         sp = __builtin_fma(c.g64[t], R64[2 * ((y + t) * ncol + x)], sp);
                         sm = __builtin_fma(c.g64[L + t], R64[2 * ((y + t) * ncol + x) + 1], sm);
                     }
