@@ -171,6 +171,12 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
     double *R64 = reinterpret_cast<double *>(rbase);
     uint8_t *const tile = TILE ? rbase + refine_r_bytes(g.n1, L, c.cbw) : nullptr;
 
+#ifdef PDOG_ABLATIONS
+    unsigned long long stamp_prev = __builtin_readcyclecounter();
+#define PDOG_STAMP(i) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(g.ex.stat + 8 + (i), now_ - stamp_prev); stamp_prev = now_; } } while (0)
+#else
+#define PDOG_STAMP(i) do { } while (0)
+#endif
     for (int p = tid; p < 256; p += NT) lut[p] = (double)p / 255.0;
     if (tid < 4) cnt[tid] = 0;
     // DC level: the same fixed sample grid as the main kernels (any level in 0…255 keeps the bound)
@@ -182,6 +188,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
     for (int w = 0; w < NW; ++w) tot += ired[w];
     const int dc = dc_from_sum(tot, g.fill);
     __syncthreads();
+    PDOG_STAMP(0);
 
     // direct = false: stages 1 + 2 (candidates → list with separable Float64 values); direct = true: every candidate
     // straight to stage 3 (list overflow).  Returns the direct mode's running peak of this thread.
@@ -227,6 +234,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                 }
                 __syncthreads();
             }
+            PDOG_STAMP(1);
             // One tile row without an LDS tile (long kernels): the thread that owns the row streams it once, 16 taps
             // at a time — 24 bytes as 6 dwords when the whole stretch lies inside the frame row — and feeds all ncol ≤ 8
             // outputs from registers (a byte load per tap and output would make this pass hundreds of µs).
@@ -295,6 +303,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                 }
             }
             __syncthreads();
+            PDOG_STAMP(2);
             const int first = min(cnt[0], REFINE_CAP);
             __syncthreads();
             // stage 1, column pass: the candidates
@@ -332,6 +341,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                 }
             }
             __syncthreads();
+            PDOG_STAMP(3);
             const int last = min(cnt[0], REFINE_CAP);
             if (!direct && last > first && !cnt[1]) {
                 // stage 2: both Gaussians' row sums in Float64 for this block's columns (R32 is dead: same memory) …
@@ -390,6 +400,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                     }
                 }
                 __syncthreads();
+                PDOG_STAMP(4);
                 // … and the new candidates' values dir·(Σ g₊[t]·R₊[y+t] − Σ g₋[t]·R₋[y+t])
                 for (int k = first + tid; k < last; k += NT) {
                     const int lin = cand_lin[k];
@@ -409,6 +420,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                     }
                     cand_val[k] = c.dir * (sp - sm);
                 }
+                PDOG_STAMP(5);
             }
             __syncthreads();
         }
@@ -451,8 +463,10 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                 peak64_push(pk, exact_pixel(frame, g.row_stride, g.fh, g.fw, g.fill, ti0 + y, wj0 + xw, L, c.K, lut), lin);
             }
         }
+        PDOG_STAMP(6);
         if (ns == 1) { __syncthreads(); return cnt[3]; }
     }
+    PDOG_STAMP(6);
     peak64_wave_reduce(pk);
     __syncthreads();
     if (lane == 0) { dred[wave] = pk.best; ired[wave] = pk.idx; }

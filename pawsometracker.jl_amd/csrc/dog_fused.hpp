@@ -125,29 +125,6 @@ __device__ __forceinline__ void fused_col_task(const f2 *a, int L, tap_ptr taps,
     }
 }
 
-// The refinement of exact mode (dog_exact.hpp) as an out-of-line call: inlined, its Float64 passes would share the
-// 128-VGPR budget of this 1024-thread kernel and push the latency path's registers to scratch.
-static __device__ __attribute__((noinline)) int fused_refine_call(const FusedGeo *fgp, const f2 *taps_row, const f2 *taps_col,
-                                                                  const uint8_t *frame, int g1, int g2, float M, unsigned char *smem)
-{
-    const FusedGeo *fg = (const FusedGeo *)uniform_u64(fgp);
-    RefineCtx c;
-    c.trow = as_taps((const f2 *)uniform_u64(taps_row));
-    c.tcol = as_taps((const f2 *)uniform_u64(taps_col));
-    c.K = (k64_ptr)uniform_u64(fg->K64);
-    c.g64 = (k64_ptr)uniform_u64(fg->g64);
-    c.dir = fg->dir;
-    c.T64 = fg->T64;
-    c.T = fg->g.ex.T;
-    c.cbw = __builtin_amdgcn_readfirstlane(fg->ref_cbw);
-    c.use_tile = 1;
-    c.lds = smem;
-    LaunchGeo g;
-    __builtin_memcpy(&g, &fg->g, sizeof g);
-    return refine_window<true>(FUSED_NT, g, (const uint8_t *)uniform_u64(frame), __builtin_amdgcn_readfirstlane(g1), __builtin_amdgcn_readfirstlane(g2),
-                               M, c, [](int, int) { return true; });
-}
-
 // DIAG != 0 (diagnostic builds only): thread 0 of block 0 stamps the phase boundaries of every frame into g.resp
 // (16 floats per frame: shader cycles since the frame's start at 0 samples reduced (wave 0), 4 after the barrier,
 // 1 tile staged, 2 row pass, 5 column pass + wave peak (wave 0), 6 after the barrier, 3 end of frame; then the same
@@ -338,7 +315,20 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
         if (s_refine) {
             // A near-tie: the reference's own arithmetic decides (dog_exact.hpp: FP32 rescan → separable Float64 →
             // sequential dense chains for genuine ties).  The tile and RT are not needed any more: their LDS is the scratch.
-            const int idx = fused_refine_call(&fg, taps_row, taps_col, frame, g1, g2, s_max, smem);
+            // (inlined: as an out-of-line call it made EVERY launch slower — 26 → 46 µs per functor call, the kernel then
+            // carries a stack; inlined, its registers spill a little into the rare path only)
+            RefineCtx c;
+            c.trow = trow;
+            c.tcol = tcol;
+            c.K = (k64_ptr)(unsigned long long)fg.K64;
+            c.g64 = (k64_ptr)(unsigned long long)fg.g64;
+            c.dir = fg.dir;
+            c.T64 = fg.T64;
+            c.T = g.ex.T;
+            c.cbw = fg.ref_cbw;
+            c.use_tile = 1;
+            c.lds = smem;
+            const int idx = refine_window<true>(NT, g, frame, g1, g2, s_max, c, [](int, int) { return true; });
             if (tid == 0) {
                 const int x = idx / g.n1, y = idx - x * g.n1;
                 const int i = min(max(g1 - g.r1 + y, 1), g.fh);

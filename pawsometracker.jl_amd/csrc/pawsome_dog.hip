@@ -906,8 +906,8 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
         CREATE_TRY(hipMemcpy(t->d_K64, K.data(), sizeof(double) * K.size(), hipMemcpyHostToDevice));
         const double delta = std::ldexp(1.0, -24) * (6.0 * t->L + 4.0) * 1.02 + 1e-9;
         t->exact_T = std::nextafter((float)(2.0 * delta), 1.0f);
-        CREATE_TRY(hipMalloc(&t->d_ref_stat, sizeof(unsigned long long) * 4));
-        CREATE_TRY(hipMemset(t->d_ref_stat, 0, sizeof(unsigned long long) * 4));
+        CREATE_TRY(hipMalloc(&t->d_ref_stat, sizeof(unsigned long long) * 16)); // [4..7] unused, [8..15]: phase cycles of the refinement (diagnostic build)
+        CREATE_TRY(hipMemset(t->d_ref_stat, 0, sizeof(unsigned long long) * 16));
         {
             std::vector<double> g2(2 * (size_t)t->L);
             std::copy(gp.begin(), gp.end(), g2.begin());
@@ -1066,9 +1066,13 @@ int pdog_get_exact_detail(pdog_tracker *t, uint64_t out[4])
     if (!t || !out) return fail(PDOG_E_ARG, "pdog_get_exact_detail: null pointer");
     HIP_TRY(hipSetDevice(t->device));
     HIP_TRY(hipStreamSynchronize(t->stream));
-    unsigned long long v[4] = {0, 0, 0, 0};
+    unsigned long long v[16];
     HIP_TRY(hipMemcpy(v, t->d_ref_stat, sizeof v, hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; ++i) out[i] = (uint64_t)v[i];
+#ifdef PDOG_ABLATIONS
+    std::fprintf(stderr, "pdog refine phases (shader cycles, thread 0): setup %llu, tile %llu, row32 %llu, col32 %llu, row64 %llu, cand64 %llu, verdict %llu\n",
+                 v[8], v[9], v[10], v[11], v[12], v[13], v[14]);
+#endif
     return PDOG_OK;
 }
 
