@@ -115,16 +115,18 @@ __device__ __forceinline__ void peak64_wave_reduce(Peak64 &p)
 //      (exact_pixel: dense l×l, sequential, kernel column-major order); a single survivor needs no evaluation at all.
 // More candidates than the list holds (plateaus: every response exactly equal) → stage 2 is skipped and every
 // candidate goes through stage 3 as it is found (right, only slow).
-constexpr int REFINE_CAP = 512; // candidate list entries
+constexpr int REFINE_CAP = 512;    // candidate list entries
+constexpr int REFINE_BLKCAP = 256; // column blocks listed for the rescan (more ⇒ every block is rescanned)
 __host__ __device__ constexpr int refine_tile_pitch(int ncol, int L) { return (ncol + L - 1 + 3) / 4 * 4; }
 // dynamic LDS of a refinement: fixed part (table p/255.0, candidate list, reductions), row-pass block (f2 for stage 1,
 // reused as 2 doubles per element for stage 2), optional pixel tile
-__host__ __device__ constexpr size_t refine_fixed_bytes() { return 256 * 8 + REFINE_CAP * 12 + 16 * 8 + 16 * 4 + 64; }
+__host__ __device__ constexpr size_t refine_fixed_bytes() { return 256 * 8 + REFINE_CAP * 12 + 16 * 8 + 16 * 4 + 32 + REFINE_BLKCAP * 4 + 32; }
 __host__ __device__ constexpr size_t refine_r_bytes(int n1, int L, int cbw) { return (size_t)(n1 + L - 1) * cbw * 16; }
-__host__ __device__ constexpr size_t refine_tile_bytes(int n1, int L, int cbw) { return ((size_t)(n1 + L - 1) * refine_tile_pitch(cbw, L) + 15) / 16 * 16; }
-__host__ __device__ constexpr size_t refine_lds_bytes(int n1, int L, int cbw, bool tile = false)
+__host__ __device__ constexpr size_t refine_tile_bytes(int rows, int L, int cbw) { return ((size_t)rows * refine_tile_pitch(cbw, L) + 15) / 16 * 16; }
+// tile_rows: rows of the block's pixel tile resident at a time (n1 + l − 1 = all of them)
+__host__ __device__ constexpr size_t refine_lds_bytes(int n1, int L, int cbw, int tile_rows)
 {
-    return refine_fixed_bytes() + refine_r_bytes(n1, L, cbw) + (tile ? refine_tile_bytes(n1, L, cbw) : 0);
+    return refine_fixed_bytes() + refine_r_bytes(n1, L, cbw) + refine_tile_bytes(tile_rows, L, cbw);
 }
 
 // bits [a, b) of a 64-column strip's lane mask (clipped to the strip)
@@ -137,6 +139,15 @@ __device__ __forceinline__ unsigned long long column_bits(int a, int b)
     return hi & ~((1ull << a) - 1ull);
 }
 
+// The refinement's constants, in device memory: the kernels that refine inline (fused, chain) carry ONE pointer to it and
+// read the fields inside the rare branch — as kernel arguments they would sit in SGPRs across the whole frame loop.
+struct RefineParams {
+    const double *K64;   // dense Float64 kernel, l×l column-major (:41-43)
+    const double *g64;   // [2][l] Float64 Gaussians
+    double dir, T64;
+};
+typedef const RefineParams __attribute__((address_space(4))) *refine_params_ptr;
+
 struct RefineCtx {
     tap_ptr trow, tcol;  // FP32 taps: (g₊, g₋)[k] and (s·g₊, −s·g₋)[k]
     k64_ptr K;           // dense Float64 kernel, l×l column-major (:41-43)
@@ -144,15 +155,16 @@ struct RefineCtx {
     double dir;          // direction, :42
     double T64;          // 2δ64
     float T;             // 2δ
-    int cbw, use_tile;
-    unsigned char *lds;  // refine_lds_bytes(n1, l, cbw, use_tile) bytes, 16-aligned
+    int cbw, tile_rows;  // window columns per block; tile rows resident at a time
+    unsigned char *lds;  // refine_lds_bytes(n1, l, cbw, tile_rows) bytes, 16-aligned
 };
 
 // `may(x0, x1)`: wave-uniform, false only if no pixel of window columns [x0, x1) can reach M − T.
+// The block's pixels go through an LDS tile of c.tile_rows rows × refine_tile_pitch bytes, staged with coalesced dword
+// loads: all NA rows at once when they fit (short kernels), otherwise slice by slice (a thread per row reading its own
+// row from memory was 10× slower: 64 cache lines per load instruction).  UNR: loads in flight per thread while staging.
 // Returns the window's answer (column-major index) in thread 0.
-// TILE: the block's pixels are staged in LDS (c.use_tile must agree); a compile-time choice so that a kernel that only
-// ever uses one of the two paths (the fused kernel always has room for the tile) does not carry the other's registers.
-template <bool TILE, typename May>
+template <int UNR, typename May>
 __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, const uint8_t *__restrict__ frame, int g1, int g2, float M,
                                              const RefineCtx &c, May may)
 {
@@ -165,11 +177,14 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
     double *dred = cand_val + REFINE_CAP;
     int *cand_lin = reinterpret_cast<int *>(dred + 16);
     int *ired = cand_lin + REFINE_CAP;
-    int *cnt = ired + 16; // [0] candidates found, [1] list overflowed, [2] survivors, [3] answer
+    int *cnt = ired + 16; // [0] candidates found, [1] list overflowed, [2] survivors, [3] answer, [4] column blocks to rescan
+    int *blk = cnt + 8;   // [REFINE_BLKCAP] first columns of the blocks to rescan
     unsigned char *rbase = c.lds + refine_fixed_bytes();
     f2 *R32 = reinterpret_cast<f2 *>(rbase);
     double *R64 = reinterpret_cast<double *>(rbase);
-    uint8_t *const tile = TILE ? rbase + refine_r_bytes(g.n1, L, c.cbw) : nullptr;
+    uint8_t *const tile = rbase + refine_r_bytes(g.n1, L, c.cbw);
+    const int RS = min(c.tile_rows, NA);       // tile rows resident at a time
+    const bool full = RS >= NA;                // the whole block's pixels stay in LDS
 
 #ifdef PDOG_ABLATIONS
     unsigned long long stamp_prev = __builtin_readcyclecounter();
@@ -178,7 +193,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
 #define PDOG_STAMP(i) do { } while (0)
 #endif
     for (int p = tid; p < 256; p += NT) lut[p] = (double)p / 255.0;
-    if (tid < 4) cnt[tid] = 0;
+    if (tid < 8) cnt[tid] = 0;
     // DC level: the same fixed sample grid as the main kernels (any level in 0…255 keeps the bound)
     int sum = dc_sample_sum(g, frame, ti0, wj0, L, tid, NT);
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
@@ -187,8 +202,51 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
     int tot = 0;
     for (int w = 0; w < NW; ++w) tot += ired[w];
     const int dc = dc_from_sum(tot, g.fill);
+    // which column blocks can hold a candidate: asked in parallel, once (a serial scan of a 513-column window's 257
+    // blocks cost 90 µs); blocks beyond the list's capacity are all rescanned
+    const int nblk_all = (g.n2 + c.cbw - 1) / c.cbw;
+    for (int cb = tid; cb < nblk_all; cb += NT)
+        if (may(cb * c.cbw, min(g.n2, (cb + 1) * c.cbw))) {
+            const int k = atomicAdd(&cnt[4], 1);
+            if (k < REFINE_BLKCAP) blk[k] = cb * c.cbw;
+        }
     __syncthreads();
+    const bool blk_all = cnt[4] > REFINE_BLKCAP;
+    const int nblk = blk_all ? nblk_all : cnt[4];
     PDOG_STAMP(0);
+
+    // rows [a0, a0 + rows) of the block's tile → LDS: a dword (4 pixels) per item, loaded unconditionally at an address
+    // clamped into the frame (a clamped dword still holds every in-frame byte its item needs, at a shifted position),
+    // the PaddedView fill (:48) selected afterwards — no branch between two loads, UNR of a thread's loads in flight
+    auto stage = [&](int x0, int tp, int a0, int rows) {
+        const int tq = tp >> 2;
+        if (g.fw >= 4) {
+#pragma unroll UNR
+            for (int e = tid; e < rows * tq; e += NT) {
+                const int a = e / tq, q = e - a * tq;
+                const int gi = ti0 + a0 + a, gj = wj0 + x0 + 4 * q;
+                const int gjc = min(max(gj, 0), g.fw - 4);
+                uint32_t w;
+                __builtin_memcpy(&w, frame + (long long)min(max(gi, 0), g.fh - 1) * g.row_stride + gjc, 4);
+                const bool rowok = gi >= 0 && gi < g.fh;
+                uint32_t o = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int gjj = gj + i;
+                    const uint32_t px = (rowok && gjj >= 0 && gjj < g.fw) ? ((w >> (8 * ((gjj - gjc) & 3))) & 0xffu) : (uint32_t)g.fill;
+                    o |= px << (8 * i);
+                }
+                *reinterpret_cast<uint32_t *>(tile + a * tp + 4 * q) = o;
+            }
+        } else {
+            for (int e = tid; e < rows * tp; e += NT) {
+                const int a = e / tp, cc = e - a * tp;
+                const int gi = ti0 + a0 + a, gj = wj0 + x0 + cc;
+                tile[e] = (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) ? frame[(long long)gi * g.row_stride + gj] : (uint8_t)g.fill;
+            }
+        }
+        __syncthreads();
+    };
 
     // direct = false: stages 1 + 2 (candidates → list with separable Float64 values); direct = true: every candidate
     // straight to stage 3 (list overflow).  Returns the direct mode's running peak of this thread.
@@ -196,76 +254,22 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
         Peak64 pk;
         pk.best = -__builtin_huge_val();
         pk.idx = 0x7fffffff;
-        for (int x0 = 0; x0 < g.n2; x0 += c.cbw) {
+        for (int bi = 0; bi < nblk; ++bi) {
+            const int x0 = blk_all ? bi * c.cbw : blk[bi];
             const int ncol = min(c.cbw, g.n2 - x0);
-            if (!may(x0, x0 + ncol)) continue;
             if (tid == 0 && !direct) atomicAdd(g.ex.stat + 1, 1ull); // column blocks rescanned (diagnostics)
             const int tp = refine_tile_pitch(ncol, L);
-            if constexpr (TILE) {
-                // A dword (4 pixels) per item.  The load is unconditional at an address clamped into the frame (a clamped
-                // dword still holds every in-frame byte its item needs, at a shifted position) and the PaddedView fill (:48)
-                // is selected afterwards: no branch between two loads, so a thread's loads are all in flight together
-                // (one memory round trip per 4 items instead of one per item: the tile is cold by now).
-                const int tq = tp >> 2;
-                if (g.fw >= 4) {
-#pragma unroll 4
-                    for (int e = tid; e < NA * tq; e += NT) {
-                        const int a = e / tq, q = e - a * tq;
-                        const int gi = ti0 + a, gj = wj0 + x0 + 4 * q;
-                        const int gjc = min(max(gj, 0), g.fw - 4);
-                        uint32_t w;
-                        __builtin_memcpy(&w, frame + (long long)min(max(gi, 0), g.fh - 1) * g.row_stride + gjc, 4);
-                        const bool rowok = gi >= 0 && gi < g.fh;
-                        uint32_t o = 0;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int gjj = gj + i;
-                            const uint32_t px = (rowok && gjj >= 0 && gjj < g.fw) ? ((w >> (8 * ((gjj - gjc) & 3))) & 0xffu) : (uint32_t)g.fill;
-                            o |= px << (8 * i);
-                        }
-                        *reinterpret_cast<uint32_t *>(tile + a * tp + 4 * q) = o;
-                    }
-                } else {
-                    for (int e = tid; e < NA * tp; e += NT) {
-                        const int a = e / tp, cc = e - a * tp;
-                        const int gi = ti0 + a, gj = wj0 + x0 + cc;
-                        tile[e] = (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) ? frame[(long long)gi * g.row_stride + gj] : (uint8_t)g.fill;
-                    }
-                }
-                __syncthreads();
-            }
-            PDOG_STAMP(1);
-            // One tile row without an LDS tile (long kernels): the thread that owns the row streams it once, 16 taps
-            // at a time — 24 bytes as 6 dwords when the whole stretch lies inside the frame row — and feeds all ncol ≤ 8
-            // outputs from registers (a byte load per tap and output would make this pass hundreds of µs).
-            auto row_chunk = [&](int a, int k0, int (&px)[24]) {
-                const int gi = ti0 + a, gj0 = wj0 + x0 + k0;
-                const bool rowok = gi >= 0 && gi < g.fh;
-                if (rowok && gj0 >= 0 && gj0 + 24 <= g.fw) {
-                    const uint8_t *src = frame + (long long)gi * g.row_stride + gj0;
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) {
-                        uint32_t w;
-                        __builtin_memcpy(&w, src + 4 * q, 4);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) px[4 * q + i] = (int)((w >> (8 * i)) & 0xffu);
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 24; ++i) {
-                        const int gj = gj0 + i;
-                        px[i] = (rowok && gj >= 0 && gj < g.fw) ? (int)frame[(long long)gi * g.row_stride + gj] : g.fill;
-                    }
-                }
-            };
-            // stage 1, row pass: R±[a][x] = Σ_k ĝ±[k]·(pixel − dc), k ascending
-            if constexpr (TILE) {
-                for (int e = tid; e < NA * ncol; e += NT) {
+            // stage 1, row pass: R±[a][x] = Σ_k ĝ±[k]·(pixel − dc), k ascending; 8 pixel reads and 8 taps requested
+            // together, only the FMAs form a chain
+            for (int a0 = 0; a0 < NA; a0 += RS) {
+                const int rows = min(RS, NA - a0);
+                stage(x0, tp, a0, rows);
+                for (int e = tid; e < rows * ncol; e += NT) {
                     const int a = e / ncol, x = e - a * ncol;
                     const uint8_t *src = tile + a * tp + x;
                     f2 acc = f2{0.f, 0.f};
                     int k = 0;
-                    for (; k + 8 <= L; k += 8) { // 8 pixel reads and 8 taps requested together; only the FMAs form a chain
+                    for (; k + 8 <= L; k += 8) {
                         float v[8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) v[u] = (float)((int)src[k + u] - dc);
@@ -273,36 +277,10 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                         for (int u = 0; u < 8; ++u) acc = fma_bcast(v[u], c.trow[k + u], acc);
                     }
                     for (; k < L; ++k) acc = fma_bcast((float)((int)src[k] - dc), c.trow[k], acc);
-                    R32[e] = acc;
+                    R32[(a0 + a) * ncol + x] = acc;
                 }
-            } else {
-                for (int a = tid; a < NA; a += NT) {
-                    f2 acc[8];
-#pragma unroll
-                    for (int x = 0; x < 8; ++x) acc[x] = f2{0.f, 0.f};
-                    int nx[24];
-                    row_chunk(a, 0, nx);
-                    for (int k0 = 0; k0 < L; k0 += 16) {
-                        int px[24];
-#pragma unroll
-                        for (int i = 0; i < 24; ++i) px[i] = nx[i];
-                        if (k0 + 16 < L) row_chunk(a, k0 + 16, nx); // the next stretch is requested before this one is consumed
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            if (k0 + u < L) {
-                                const f2 t = c.trow[k0 + u];
-#pragma unroll
-                                for (int x = 0; x < 8; ++x)
-                                    if (x < ncol) acc[x] = fma_bcast((float)(px[u + x] - dc), t, acc[x]);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int x = 0; x < 8; ++x)
-                        if (x < ncol) R32[a * ncol + x] = acc[x];
-                }
+                __syncthreads();
             }
-            __syncthreads();
             PDOG_STAMP(2);
             const int first = min(cnt[0], REFINE_CAP);
             __syncthreads();
@@ -331,7 +309,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                 if (acc >= thr) {
                     const int lin = (x0 + x) * g.n1 + y;
                     if (direct) {
-                        const double F = TILE ? exact_patch((const uint8_t *)(tile + y * tp + x), (long long)tp, L, c.K, lut)
+                        const double F = full ? exact_patch((const uint8_t *)(tile + y * tp + x), (long long)tp, L, c.K, lut)
                                               : exact_pixel(frame, g.row_stride, g.fh, g.fw, g.fill, ti0 + y, wj0 + x0 + x, L, c.K, lut);
                         peak64_push(pk, F, lin);
                     } else {
@@ -345,8 +323,10 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
             const int last = min(cnt[0], REFINE_CAP);
             if (!direct && last > first && !cnt[1]) {
                 // stage 2: both Gaussians' row sums in Float64 for this block's columns (R32 is dead: same memory) …
-                if constexpr (TILE) {
-                    for (int e = tid; e < NA * ncol; e += NT) {
+                for (int a0 = 0; a0 < NA; a0 += RS) {
+                    const int rows = min(RS, NA - a0);
+                    if (!full) stage(x0, tp, a0, rows); // (a fully resident tile is still there)
+                    for (int e = tid; e < rows * ncol; e += NT) {
                         const int a = e / ncol, x = e - a * ncol;
                         const uint8_t *src = tile + a * tp + x;
                         double sp = 0.0, sm = 0.0;
@@ -366,40 +346,11 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                             sp = __builtin_fma(c.g64[k], v, sp);
                             sm = __builtin_fma(c.g64[L + k], v, sm);
                         }
-                        R64[2 * e] = sp;
-                        R64[2 * e + 1] = sm;
+                        R64[2 * ((a0 + a) * ncol + x)] = sp;
+                        R64[2 * ((a0 + a) * ncol + x) + 1] = sm;
                     }
-                } else {
-                    for (int a = tid; a < NA; a += NT) {
-                        double sp[8], sm[8];
-#pragma unroll
-                        for (int x = 0; x < 8; ++x) sp[x] = sm[x] = 0.0;
-                        int nx[24];
-                        row_chunk(a, 0, nx);
-                        for (int k0 = 0; k0 < L; k0 += 16) {
-                            int px[24];
-#pragma unroll
-                            for (int i = 0; i < 24; ++i) px[i] = nx[i];
-                            if (k0 + 16 < L) row_chunk(a, k0 + 16, nx);
-                            double v[24];
-#pragma unroll
-                            for (int i = 0; i < 24; ++i) v[i] = lut[px[i]];
-#pragma unroll
-                            for (int u = 0; u < 16; ++u) {
-                                if (k0 + u < L) {
-                                    const double gp = c.g64[k0 + u], gm = c.g64[L + k0 + u];
-#pragma unroll
-                                    for (int x = 0; x < 8; ++x)
-                                        if (x < ncol) { sp[x] = __builtin_fma(gp, v[u + x], sp[x]); sm[x] = __builtin_fma(gm, v[u + x], sm[x]); }
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int x = 0; x < 8; ++x)
-                            if (x < ncol) { R64[2 * (a * ncol + x)] = sp[x]; R64[2 * (a * ncol + x) + 1] = sm[x]; }
-                    }
+                    __syncthreads();
                 }
-                __syncthreads();
                 PDOG_STAMP(4);
                 // … and the new candidates' values dir·(Σ g₊[t]·R₊[y+t] − Σ g₋[t]·R₋[y+t])
                 for (int k = first + tid; k < last; k += NT) {
@@ -446,10 +397,10 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
         // compact the survivors to the front of the list (order is irrelevant: ties are settled by index)
         for (int k0 = 0; k0 < n; k0 += NT) {
             const int k = k0 + tid;
-            const bool s = k < n && cand_val[k] >= keep;
-            const int lin = s ? cand_lin[k] : 0;
+            const bool sv = k < n && cand_val[k] >= keep;
+            const int lin = sv ? cand_lin[k] : 0;
             __syncthreads();
-            if (s) cand_lin[atomicAdd(&cnt[2], 1)] = lin; // lands below k0 + NT: every entry there has been read already
+            if (sv) cand_lin[atomicAdd(&cnt[2], 1)] = lin; // lands below k0 + NT: every entry there has been read already
             __syncthreads();
         }
         const int ns = cnt[2];
@@ -466,7 +417,6 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
         PDOG_STAMP(6);
         if (ns == 1) { __syncthreads(); return cnt[3]; }
     }
-    PDOG_STAMP(6);
     peak64_wave_reduce(pk);
     __syncthreads();
     if (lane == 0) { dred[wave] = pk.best; ired[wave] = pk.idx; }
@@ -488,7 +438,7 @@ struct FinishGeo {
     const double *K64;           // l×l, column-major, dir·(g₊⊗g₊ − g₋⊗g₋) (:41-43); null = exact mode off
     const double *g64;           // [2][l] Float64 Gaussians
     double dir, T64;
-    int cbw, use_tile;
+    int cbw, tile_rows;
     // how the partial slots map to window columns: slot s < nmain covers [min(s·slot_w, slot_last) … + slot_w) (the
     // roll kernel shifts its last strip left: slot_last = covered − slot_w; others: slot_last = huge), slots ≥ nmain
     // are single columns thin_x0 + (s − nmain)
@@ -545,7 +495,7 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
     c.T64 = fg.T64;
     c.T = g.ex.T;
     c.cbw = fg.cbw;
-    c.use_tile = fg.use_tile;
+    c.tile_rows = fg.tile_rows;
     c.lds = smem;
     // the slots' maxima and column masks once, into LDS: `may` is asked once per column block
     constexpr int SLOT_CAP = 128;
@@ -577,7 +527,7 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
         }
         return false;
     };
-    const int idx = fg.use_tile ? refine_window<true>(NT, g, frame, g1, g2, s_max, c, may) : refine_window<false>(NT, g, frame, g1, g2, s_max, c, may);
+    const int idx = refine_window<16>(NT, g, frame, g1, g2, s_max, c, may);
     if (tid == 0) {
         const int x = idx / g.n1, y = idx - x * g.n1;
         fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);

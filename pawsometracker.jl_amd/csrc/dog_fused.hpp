@@ -33,10 +33,8 @@ struct FusedGeo {
     int32_t *done_flag;  // NULL, or a word in host-coherent memory that receives done_value (system-scope release) once
     int32_t done_value;  // window 0's answer is written: the host functor polls it instead of waiting for the kernel's end
     int progress;        // != 0: done_flag receives k + 1 after every frame k of clip 0 instead (a host consumer follows the chain)
-    const double *K64;   // the reference's dense Float64 kernel, l×l column-major (exact mode, dog_exact.hpp); null = off
-    const double *g64;   // [2][l] Float64 Gaussians (the refinement's separable stage)
-    double dir, T64;
-    int ref_cbw;         // the refinement's column-block width (its scratch — row-pass block AND pixel tile — is this kernel's dynamic LDS)
+    const RefineParams *rp; // exact mode's constants in device memory (dog_exact.hpp); null = off
+    int ref_cbw, ref_rows; // the refinement's column-block width and resident tile rows (its scratch is this kernel's dynamic LDS)
 };
 
 constexpr int FUSED_NT = 1024, FUSED_PMAX = 8, FUSED_U = 8;
@@ -303,7 +301,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
                 s_guess[1] = j;
                 if (k == 0) range_check(g.ex, g1, g2, hw, g.fh, g.fw);
                 // exact mode (dog_exact.hpp): a runner-up within 2δ of the maximum → the reference's own arithmetic decides
-                const bool rf = fg.K64 && (pk.best - pk.second <= g.ex.T);
+                const bool rf = fg.rp && (pk.best - pk.second <= g.ex.T);
                 s_refine = rf;
                 s_max = pk.best;
                 if (rf) atomicAdd(g.ex.stat, 1ull);
@@ -317,18 +315,19 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
             // sequential dense chains for genuine ties).  The tile and RT are not needed any more: their LDS is the scratch.
             // (inlined: as an out-of-line call it made EVERY launch slower — 26 → 46 µs per functor call, the kernel then
             // carries a stack; inlined, its registers spill a little into the rare path only)
+            const refine_params_ptr rp = (refine_params_ptr)(unsigned long long)fg.rp; // read here, in the rare branch
             RefineCtx c;
             c.trow = trow;
             c.tcol = tcol;
-            c.K = (k64_ptr)(unsigned long long)fg.K64;
-            c.g64 = (k64_ptr)(unsigned long long)fg.g64;
-            c.dir = fg.dir;
-            c.T64 = fg.T64;
+            c.K = (k64_ptr)(unsigned long long)rp->K64;
+            c.g64 = (k64_ptr)(unsigned long long)rp->g64;
+            c.dir = rp->dir;
+            c.T64 = rp->T64;
             c.T = g.ex.T;
             c.cbw = fg.ref_cbw;
-            c.use_tile = 1;
+            c.tile_rows = fg.ref_rows;
             c.lds = smem;
-            const int idx = refine_window<true>(NT, g, frame, g1, g2, s_max, c, [](int, int) { return true; });
+            const int idx = refine_window<4>(NT, g, frame, g1, g2, s_max, c, [](int, int) { return true; });
             if (tid == 0) {
                 const int x = idx / g.n1, y = idx - x * g.n1;
                 const int i = min(max(g1 - g.r1 + y, 1), g.fh);

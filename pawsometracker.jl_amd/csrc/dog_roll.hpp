@@ -506,10 +506,8 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
 // columns are not used here: the last strip overlaps instead (bit-identical values either way).
 struct ChainGeo {
     LaunchGeo g;                         // frames = first frame of clip 0; guesses/frame_index unused
-    const double *K64;                   // the reference's dense Float64 kernel (exact mode; null = off), dog_exact.hpp
-    const double *g64;                   // [2][l] Float64 Gaussians (the refinement's separable stage)
-    double dir, T64;
-    int ref_cbw, ref_tile;               // refinement inside the kernel: window columns per block; pixel tile staged in LDS (the strips' LDS is its scratch)
+    const RefineParams *rp;              // exact mode's constants in device memory (dog_exact.hpp); null = off
+    int ref_cbw, ref_rows;               // refinement inside the kernel: window columns per block; tile rows resident at a time (the strips' LDS is its scratch)
     const f2 *taps_col_plain;            // (s·g₊[k], −s·g₋[k]) per tap: the refinement's column taps (taps_col is the roll kernel's paired table)
     const int *__restrict__ start;       // n_clips x 2, 1-based (row, col)
     int *__restrict__ out_ij;            // n_clips x n_frames x 2
@@ -553,7 +551,7 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
             int *o = cg.out_ij + 2 * ((long long)c_ * cg.n_frames + k);
             o[0] = i; o[1] = j;
             cur[0] = i; cur[1] = j;
-            s_refine = cg.K64 && (w.best - w.second <= g.ex.T);
+            s_refine = cg.rp && (w.best - w.second <= g.ex.T);
             s_max = w.best;
             if (s_refine) atomicAdd(g.ex.stat, 1ull);
         }
@@ -564,13 +562,14 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
             RefineCtx c;
             c.trow = as_taps(taps_row);
             c.tcol = as_taps(cg.taps_col_plain);
-            c.K = (k64_ptr)(unsigned long long)cg.K64;
-            c.g64 = (k64_ptr)(unsigned long long)cg.g64;
-            c.dir = cg.dir;
-            c.T64 = cg.T64;
+            const refine_params_ptr rp = (refine_params_ptr)(unsigned long long)cg.rp;
+            c.K = (k64_ptr)(unsigned long long)rp->K64;
+            c.g64 = (k64_ptr)(unsigned long long)rp->g64;
+            c.dir = rp->dir;
+            c.T64 = rp->T64;
             c.T = g.ex.T;
             c.cbw = cg.ref_cbw;
-            c.use_tile = cg.ref_tile;
+            c.tile_rows = cg.ref_rows;
             c.lds = smem;
             const float thr = s_max - g.ex.T;
             auto may = [&](int x0, int x1) { // strip s covers 64 columns from min(64 s, n2 − 64) (one partial strip when n2 < 64)
@@ -581,8 +580,7 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
                 }
                 return any;
             };
-            const int idx = cg.ref_tile ? refine_window<true>(blockDim.x, g, frame, g1, g2, s_max, c, may)
-                                        : refine_window<false>(blockDim.x, g, frame, g1, g2, s_max, c, may);
+            const int idx = refine_window<8>(blockDim.x, g, frame, g1, g2, s_max, c, may);
             if (tid == 0) {
                 const int x = idx / g.n1, y = idx - x * g.n1;
                 const int i = min(max(g1 - g.r1 + y, 1), g.fh);

@@ -252,12 +252,11 @@ struct pdog_tracker {
     float exact_T = 0.f;              // 2δ
     double *d_K64 = nullptr;          // dir·(g₊⊗g₊ − g₋⊗g₋), l×l column-major, Float64 (:41-43)
     double *d_g64 = nullptr;          // [2][l] the two normalised Gaussians in Float64 (the refinement's separable stage)
+    RefineParams *d_rp = nullptr;     // {K64, g64, dir, T64} for the kernels that refine inline
     double exact_T64 = 0.0;           // 2δ64: separable Float64 against the reference's dense Float64
     unsigned long long *d_ref_stat = nullptr;
-    int ref_cbw = 1;                  // window columns per block of the refinement
-    bool ref_tile = false;            // the refinement stages its block's pixels in LDS
-    int fused_ref_cbw = 1;            // the same for the refinement inside the fused kernel (its scratch is that kernel's LDS)
-    bool fused_ref_tile = false;
+    int ref_cbw = 1, ref_rows = 8;    // refinement: window columns per block; rows of the block's pixel tile resident in LDS at a time
+    int fused_ref_cbw = 1, fused_ref_rows = 8; // the same inside the fused kernel (its scratch is that kernel's LDS)
     // host-path staging (pdog_detect_host / chain seed)
     uint8_t *d_frame = nullptr;
     int32_t *d_small = nullptr; // [0..1] guess, [2..3] result
@@ -289,24 +288,30 @@ fused_fn_t fused_kernel_for(int L, bool resp);
 int twopass_pitch(int nout, int L, int rows = HP_ROWS) { return (round_up(nout, rows == 8 ? 32 * 7 : 16 * 13) + L + 16) | 1; }
 
 // Exact mode's refinement (dog_exact.hpp) works on blocks of `cbw` window columns whose row-pass result (two doubles
-// per element in the Float64 stage) fits ≈24 KB of LDS; the block's pixels go to LDS too when everything fits 100 KB
-// (l ≲ 150): a candidate's chain then reads LDS instead of waiting for memory once per term.
+// per element in the Float64 stage) fits ≈24 KB of LDS; the block's pixels go through an LDS tile — all n1 + l − 1 rows
+// resident when that fits 100 KB in total (l ≲ 150: a candidate's exact chain then reads LDS), otherwise ≈24 KB slices.
+int refine_slice_rows(int NA, int L, int cbw, size_t budget)
+{
+    return (int)std::max<size_t>(8, std::min<size_t>((size_t)NA, budget / (size_t)refine_tile_pitch(cbw, L)));
+}
 void setup_refine_geometry(pdog_tracker *t)
 {
     const int NA = t->n1 + t->L - 1;
     t->ref_cbw = std::max(1, std::min({8, t->n2, (int)(24576 / ((size_t)NA * 16))}));
-    t->ref_tile = refine_lds_bytes(t->n1, t->L, t->ref_cbw, true) <= 100 * 1024; // (one workgroup per CU beyond 80 KB: fine for a kernel whose blocks mostly exit at once)
-    // inside the fused kernel the scratch is that kernel's own LDS (tile + RT, free by then): the widest block that fits it
+    t->ref_rows = refine_lds_bytes(t->n1, t->L, t->ref_cbw, NA) <= 100 * 1024 ? NA : refine_slice_rows(NA, t->L, t->ref_cbw, 24576);
+    // inside the fused kernel the scratch is that kernel's own LDS (tile + RT, free by then): the widest block that fits
+    // it with the whole pixel tile resident (a window whose tile fits as floats has room for it as bytes)
     t->fused_ref_cbw = 1;
-    t->fused_ref_tile = true; // always: a window whose tile + RT fit in LDS as floats has room for its pixels as bytes
+    t->fused_ref_rows = NA;
     const size_t have = fused_lds_bytes(t->n1, t->n2, t->L);
     for (int cbw = std::min(8, t->n2); cbw >= 1; --cbw)
-        if (refine_lds_bytes(t->n1, t->L, cbw, true) <= have) { t->fused_ref_cbw = cbw; break; }
+        if (refine_lds_bytes(t->n1, t->L, cbw, NA) <= have) { t->fused_ref_cbw = cbw; break; }
+    if (refine_lds_bytes(t->n1, t->L, 1, NA) > kMaxLds - 1024) t->fused_ref_rows = refine_slice_rows(NA, t->L, 1, 24576);
 }
 // dynamic LDS of the fused kernel: its tile + RT, or the scratch of the refinement it may run in the same memory
 size_t fused_total_lds(const pdog_tracker *t)
 {
-    return std::max(fused_lds_bytes(t->n1, t->n2, t->L), refine_lds_bytes(t->n1, t->L, t->fused_ref_cbw, t->fused_ref_tile));
+    return std::max(fused_lds_bytes(t->n1, t->n2, t->L), refine_lds_bytes(t->n1, t->L, t->fused_ref_cbw, t->fused_ref_rows));
 }
 
 int choose_variant(pdog_tracker *t, int forced)
@@ -482,7 +487,7 @@ int launch_finish(pdog_tracker *t, const LaunchGeo &g, int slot_w, int slot_last
     fg.dir = t->darker ? -1.0 : 1.0;
     fg.T64 = t->exact_T64;
     fg.cbw = t->ref_cbw;
-    fg.use_tile = t->ref_tile ? 1 : 0;
+    fg.tile_rows = t->ref_rows;
     fg.slot_w = slot_w;
     fg.slot_last = slot_last;
     fg.nmain = g.nslots - g.nthin;
@@ -491,7 +496,7 @@ int launch_finish(pdog_tracker *t, const LaunchGeo &g, int slot_w, int slot_last
     fg.out_ij = d_out_ij;
     fg.done_flag = d_done_flag;
     fg.done_value = done_value;
-    const size_t lds = t->exact ? refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_tile) : 0;
+    const size_t lds = t->exact ? refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_rows) : 0;
     hipLaunchKernelGGL(dog_finish_kernel, dim3(g.n), dim3(REFINE_NT), lds, t->stream, fg, (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
     HIP_TRY(hipGetLastError());
     return PDOG_OK;
@@ -538,11 +543,9 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     fg.done_flag = d_done_flag;
     fg.done_value = done_value;
     fg.progress = progress ? 1 : 0;
-    fg.K64 = t->exact ? t->d_K64 : nullptr;
-    fg.g64 = t->d_g64;
-    fg.dir = t->darker ? -1.0 : 1.0;
-    fg.T64 = t->exact_T64;
+    fg.rp = t->exact ? t->d_rp : nullptr;
     fg.ref_cbw = t->fused_ref_cbw;
+    fg.ref_rows = t->fused_ref_rows;
     g.ex = exact_ctl(t);
     const size_t lds = fused_total_lds(t);
     typedef fused_fn_t fused_fn;
@@ -917,8 +920,17 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
         }
         // separable Float64 vs the reference's dense Float64 (l² sequential roundings): both within δ64 of the exact value
         t->exact_T64 = 2.0 * std::ldexp(1.0, -53) * (2.1 * t->L * t->L + 8.0 * t->L + 64.0);
-        t->exact = !t->sw.no_exact && refine_lds_bytes(t->n1, t->L, 1, false) <= kMaxLds - 8192;
-        if (raise_lds_limit((const void *)dog_finish_kernel, refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_tile))) { pdog_destroy(t); return PDOG_E_HIP; }
+        {
+            RefineParams rp;
+            rp.K64 = t->d_K64;
+            rp.g64 = t->d_g64;
+            rp.dir = t->darker ? -1.0 : 1.0;
+            rp.T64 = t->exact_T64;
+            CREATE_TRY(hipMalloc(&t->d_rp, sizeof rp));
+            CREATE_TRY(hipMemcpy(t->d_rp, &rp, sizeof rp, hipMemcpyHostToDevice));
+        }
+        t->exact = !t->sw.no_exact && refine_lds_bytes(t->n1, t->L, 1, 8) <= kMaxLds - 8192;
+        if (raise_lds_limit((const void *)dog_finish_kernel, refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_rows))) { pdog_destroy(t); return PDOG_E_HIP; }
     }
 #undef CREATE_TRY
     rc = ensure_capacity(t, 1);
@@ -935,7 +947,7 @@ int pdog_destroy(pdog_tracker *t)
     if (t->d_taps_row) (void)hipFree(t->d_taps_row);
     if (t->d_taps_col) (void)hipFree(t->d_taps_col);
     if (t->d_taps_roll) (void)hipFree(t->d_taps_roll);
-    for (void *p : {(void *)t->d_part_val, (void *)t->d_part_idx, (void *)t->d_part_sec, (void *)t->d_part_mask, (void *)t->d_K64, (void *)t->d_g64,
+    for (void *p : {(void *)t->d_part_val, (void *)t->d_part_idx, (void *)t->d_part_sec, (void *)t->d_part_mask, (void *)t->d_K64, (void *)t->d_g64, (void *)t->d_rp,
                     (void *)t->d_ref_stat})
         if (p) (void)hipFree(p);
     if (t->d_frame) (void)hipFree(t->d_frame);
@@ -1053,7 +1065,7 @@ int pdog_sync(pdog_tracker *t)
 int pdog_set_exact(pdog_tracker *t, int on)
 {
     if (!t) return fail(PDOG_E_ARG, "pdog_set_exact: null tracker");
-    if (on && refine_lds_bytes(t->n1, t->L, 1, false) > kMaxLds - 8192)
+    if (on && refine_lds_bytes(t->n1, t->L, 1, 8) > kMaxLds - 8192)
         return fail(PDOG_E_ARG, "pdog_set_exact: window too tall for the refinement's LDS block");
     HIP_TRY(hipStreamSynchronize(t->stream));
     t->exact = on != 0;
@@ -1468,19 +1480,22 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
         cg.out_ij = d_out_ij;
         cg.n_frames = n_frames;
         g.ex = exact_ctl(t);
-        cg.K64 = t->exact ? t->d_K64 : nullptr;
-        cg.g64 = t->d_g64;
-        cg.dir = t->darker ? -1.0 : 1.0;
-        cg.T64 = t->exact_T64;
+        cg.rp = t->exact ? t->d_rp : nullptr;
         cg.taps_col_plain = t->d_taps_col;
         // the strips' LDS doubles as the refinement's scratch: the widest block (with its pixel tile if possible) that
         // fits what the strips need anyway, so that exact mode does not cost the chain kernel occupancy
-        const size_t base = std::max((size_t)chain_strips * roll_lds_bytes(v.LT), refine_lds_bytes(t->n1, t->L, 1, false));
+        const int NAc = t->n1 + t->L - 1;
+        const size_t base = std::max((size_t)chain_strips * roll_lds_bytes(v.LT), refine_lds_bytes(t->n1, t->L, 1, 8));
         cg.ref_cbw = 1;
-        cg.ref_tile = 0;
-        for (int tile = 1; tile >= 0 && cg.ref_cbw == 1 && !cg.ref_tile; --tile)
-            for (int cbw = std::min(t->n2, t->ref_cbw); cbw >= 1; --cbw)
-                if (refine_lds_bytes(t->n1, t->L, cbw, tile != 0) <= base) { cg.ref_cbw = cbw; cg.ref_tile = tile; break; }
+        cg.ref_rows = 8;
+        for (int cbw = std::min(t->n2, t->ref_cbw); cbw >= 1; --cbw) { // widest block first; its tile fully resident if possible, else the tallest slice
+            const size_t fixed_r = refine_lds_bytes(t->n1, t->L, cbw, 0);
+            if (fixed_r + (size_t)8 * refine_tile_pitch(cbw, t->L) > base) continue;
+            cg.ref_cbw = cbw;
+            cg.ref_rows = (int)std::min<size_t>((size_t)NAc, (base - fixed_r) / (size_t)refine_tile_pitch(cbw, t->L));
+            while (cg.ref_rows > 8 && refine_lds_bytes(t->n1, t->L, cbw, cg.ref_rows) > base) --cg.ref_rows;
+            break;
+        }
         const size_t lds = base;
         if (int rc = raise_lds_limit((const void *)v.chain, lds)) return rc;
         hipLaunchKernelGGL(v.chain, dim3(n_clips), dim3(64 * chain_strips), lds, t->stream, cg,
