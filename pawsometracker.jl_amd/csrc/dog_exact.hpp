@@ -164,8 +164,7 @@ struct RefineCtx {
 // loads: all NA rows at once when they fit (short kernels), otherwise slice by slice (a thread per row reading its own
 // row from memory was 10× slower: 64 cache lines per load instruction).  UNR: loads in flight per thread while staging.
 // Returns the window's answer (column-major index) in thread 0.
-// ROWWISE: the row passes run a thread per tile row (fastest, but ≈150 VGPRs: not for the 1024-thread fused kernel).
-template <int UNR, bool ROWWISE, typename May>
+template <int UNR, typename May>
 __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, const uint8_t *__restrict__ frame, int g1, int g2, float M,
                                              const RefineCtx &c, May may)
 {
@@ -265,38 +264,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
             for (int a0 = 0; a0 < NA; a0 += RS) {
                 const int rows = min(RS, NA - a0);
                 stage(x0, tp, a0, rows);
-                if constexpr (ROWWISE) {
-                // a thread per tile row: the row's bytes come out of LDS as aligned dwords, 24 pixels per 16 taps, and
-                // feed all ncol ≤ 8 outputs from registers (one byte read per tap and output was 4× the instructions)
-                for (int a = tid; a < rows; a += NT) {
-                    const uint32_t *src = reinterpret_cast<const uint32_t *>(tile + a * tp);
-                    f2 acc[8];
-#pragma unroll
-                    for (int x = 0; x < 8; ++x) acc[x] = f2{0.f, 0.f};
-                    for (int k0 = 0; k0 < L; k0 += 16) {
-                        float v[24];
-#pragma unroll
-                        for (int q = 0; q < 6; ++q) {
-                            const uint32_t w = (k0 + 4 * q < tp) ? src[(k0 >> 2) + q] : 0u;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) v[4 * q + i] = (float)((int)((w >> (8 * i)) & 0xffu) - dc);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            if (k0 + u < L) {
-                                const f2 t = c.trow[k0 + u];
-#pragma unroll
-                                for (int x = 0; x < 8; ++x)
-                                    if (x < ncol) acc[x] = fma_bcast(v[u + x], t, acc[x]);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int x = 0; x < 8; ++x)
-                        if (x < ncol) R32[(a0 + a) * ncol + x] = acc[x];
-                }
-                } else {
-                for (int e = tid; e < rows * ncol; e += NT) { // an item per (row, column): 8 pixel reads and 8 taps requested together
+                for (int e = tid; e < rows * ncol; e += NT) {
                     const int a = e / ncol, x = e - a * ncol;
                     const uint8_t *src = tile + a * tp + x;
                     f2 acc = f2{0.f, 0.f};
@@ -310,7 +278,6 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                     }
                     for (; k < L; ++k) acc = fma_bcast((float)((int)src[k] - dc), c.trow[k], acc);
                     R32[(a0 + a) * ncol + x] = acc;
-                }
                 }
                 __syncthreads();
             }
@@ -359,35 +326,6 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                 for (int a0 = 0; a0 < NA; a0 += RS) {
                     const int rows = min(RS, NA - a0);
                     if (!full) stage(x0, tp, a0, rows); // (a fully resident tile is still there)
-                    if constexpr (ROWWISE) {
-                    for (int a = tid; a < rows; a += NT) { // a thread per tile row, as in the FP32 row pass
-                        const uint32_t *src = reinterpret_cast<const uint32_t *>(tile + a * tp);
-                        double sp[8], sm[8];
-#pragma unroll
-                        for (int x = 0; x < 8; ++x) sp[x] = sm[x] = 0.0;
-                        for (int k0 = 0; k0 < L; k0 += 16) {
-                            double v[24];
-#pragma unroll
-                            for (int q = 0; q < 6; ++q) {
-                                const uint32_t w = (k0 + 4 * q < tp) ? src[(k0 >> 2) + q] : 0u;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) v[4 * q + i] = lut[(w >> (8 * i)) & 0xffu];
-                            }
-#pragma unroll
-                            for (int u = 0; u < 16; ++u) {
-                                if (k0 + u < L) {
-                                    const double gp = c.g64[k0 + u], gm = c.g64[L + k0 + u];
-#pragma unroll
-                                    for (int x = 0; x < 8; ++x)
-                                        if (x < ncol) { sp[x] = __builtin_fma(gp, v[u + x], sp[x]); sm[x] = __builtin_fma(gm, v[u + x], sm[x]); }
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int x = 0; x < 8; ++x)
-                            if (x < ncol) { R64[2 * ((a0 + a) * ncol + x)] = sp[x]; R64[2 * ((a0 + a) * ncol + x) + 1] = sm[x]; }
-                    }
-                    } else {
                     for (int e = tid; e < rows * ncol; e += NT) {
                         const int a = e / ncol, x = e - a * ncol;
                         const uint8_t *src = tile + a * tp + x;
@@ -410,7 +348,6 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                         }
                         R64[2 * ((a0 + a) * ncol + x)] = sp;
                         R64[2 * ((a0 + a) * ncol + x) + 1] = sm;
-                    }
                     }
                     __syncthreads();
                 }
@@ -590,7 +527,7 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
         }
         return false;
     };
-    const int idx = refine_window<16, true>(NT, g, frame, g1, g2, s_max, c, may);
+    const int idx = refine_window<16>(NT, g, frame, g1, g2, s_max, c, may);
     if (tid == 0) {
         const int x = idx / g.n1, y = idx - x * g.n1;
         fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);

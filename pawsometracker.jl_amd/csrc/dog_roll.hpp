@@ -580,7 +580,7 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
                 }
                 return any;
             };
-            const int idx = refine_window<8, true>(blockDim.x, g, frame, g1, g2, s_max, c, may);
+            const int idx = refine_window<8>(blockDim.x, g, frame, g1, g2, s_max, c, may);
             if (tid == 0) {
                 const int x = idx / g.n1, y = idx - x * g.n1;
                 const int i = min(max(g1 - g.r1 + y, 1), g.fh);
