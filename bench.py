@@ -150,6 +150,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=0, help="override windows per GPU")
     ap.add_argument("--noise", type=int, default=3, help="± uniform noise levels on the synthetic frames")
     ap.add_argument("--variant", type=int, default=-1, help="force a kernel specialisation")
+    ap.add_argument("--target-width", type=float, default=0.0, help="override the workload's target_width (tuning: other kernel lengths)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--data-rank", type=int, default=-1, help="generate the synthetic data of this rank (checks the per-rank seeds on one GPU)")
     ap.add_argument("--group", action="store_true",
@@ -321,6 +322,8 @@ def main():
     fh, fw, tw, ws, batch, desc = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
+    if args.target_width:
+        tw, desc = args.target_width, desc + f" [target_width overridden: {args.target_width}]"
     ws = pt.fix_window_size(ws if not isinstance(ws, tuple) else (ws[1], ws[0]))   # (w,h) -> (h,w), :70
     radii = (ws[0] // 2, ws[1] // 2)
     fill = 128

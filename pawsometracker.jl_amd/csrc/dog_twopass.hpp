@@ -59,23 +59,21 @@ static __global__ __launch_bounds__(64) void dog_dc_kernel(const LaunchGeo g, in
 constexpr int HP_ROWS = 16; // rows per workgroup in both passes
 // DCIN: the workgroup derives the window's DC level itself (the same 1024 integer samples, 4 per thread) instead of
 // reading the result of dog_dc_kernel: one launch less where launches are what a small batch costs.
-template <int P, int U, bool DCIN = false>
-__global__ __launch_bounds__(256) void dog_h1_kernel(const TwoPassGeo tg, const f2 *__restrict__ taps_row)
+// One row-pass workgroup's work: tile rows 16·rb … of the window whose RT block is `b_local`, read from `frame` around
+// guess (g1, g2).  DCIN: derive the DC level here; otherwise dc_in is used.  (The kernels below and the cooperative
+// single-clip chain, dog_coop.hpp, share it.)
+template <int P, int U, bool DCIN>
+__device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restrict__ taps_row, unsigned char *smem, int b_local, int rb,
+                                         const uint8_t *__restrict__ frame, int g1, int g2, int dc_in)
 {
     const LaunchGeo &g = tg.g;
     constexpr int NT = 256, NW = NT / 64, XG = NT / HP_ROWS;
     const int L = g.L, H = L >> 1, hw = L >> 1;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *A = reinterpret_cast<float *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b_local = blockIdx.x / tg.h1blocks_per_win;
-    const int rb = blockIdx.x - b_local * tg.h1blocks_per_win;
-    const int b = tg.win0 + b_local;
     const int a0 = rb * HP_ROWS;
-    const int fidx = g.frame_index ? g.frame_index[b] : b;
-    const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
-    const int ti0 = g.guesses[2 * b] - g.r1 - 1 - hw;
-    const int wj0 = g.guesses[2 * b + 1] - g.r2 - 1 - hw;
+    const int ti0 = g1 - g.r1 - 1 - hw;
+    const int wj0 = g2 - g.r2 - 1 - hw;
     int dc;
     if (DCIN) {
         __shared__ int s_dcsum[NW];
@@ -89,7 +87,7 @@ __global__ __launch_bounds__(256) void dog_h1_kernel(const TwoPassGeo tg, const 
         for (int w = 0; w < NW; ++w) total += s_dcsum[w];
         dc = dc_from_sum(total, g.fill);
     } else {
-        dc = tg.dc[b];
+        dc = dc_in;
     }
     // stage 16 tile rows as f32 (pixel − dc); outside the frame = fill − dc.  The row is staged out to the LDS pitch
     // (zeros past the tile): the sliding windows of the last, partly masked output group then read in-bounds
@@ -187,24 +185,35 @@ __global__ __launch_bounds__(256) void dog_h1_kernel(const TwoPassGeo tg, const 
     }
 }
 
+template <int P, int U, bool DCIN = false>
+__global__ __launch_bounds__(256) void dog_h1_kernel(const TwoPassGeo tg, const f2 *__restrict__ taps_row)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const LaunchGeo &g = tg.g;
+    const int b_local = blockIdx.x / tg.h1blocks_per_win;
+    const int rb = blockIdx.x - b_local * tg.h1blocks_per_win;
+    const int b = tg.win0 + b_local;
+    const int fidx = g.frame_index ? g.frame_index[b] : b;
+    h1_block<P, U, DCIN>(tg, taps_row, smem, b_local, rb, g.frames + (long long)fidx * g.frame_stride, g.guesses[2 * b], g.guesses[2 * b + 1],
+                         DCIN ? 0 : tg.dc[b]);
+}
+
 // ---- column pass + peak (on RT) ----
 // FIN: the workgroup that delivers a window's last partial also combines them, maps the index and clamps
 // (dog_finalize_kernel's job, :60-61) — no separate launch.  Partials cross workgroups through L2: release fence +
 // device-scope counter on the writer side, device-scope loads on the reader side; the counter is left at zero.
-template <int P, int U, bool RESP, int HR = HP_ROWS, bool FIN = false>
-__global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, const f2 *__restrict__ taps_col)
+// One column-pass workgroup's work on RT block `b_local`, window columns HR·rb …: the workgroup's peak, valid in thread 0
+// (ends with a barrier: the caller may reuse the LDS).  b: the window's index for the optional response output.
+template <int P, int U, bool RESP, int HR>
+__device__ __forceinline__ Peak hpass_block(const TwoPassGeo &tg, const f2 *__restrict__ taps_col, unsigned char *smem, int b_local, int rb, int b)
 {
     const LaunchGeo &g = tg.g;
     constexpr int NT = 256, NW = NT / 64, XG = NT / HR;
     const int L = g.L;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f2 *Vs = reinterpret_cast<f2 *>(smem);
     __shared__ float sval[NW], ssec[NW];
     __shared__ int sidx[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b_local = blockIdx.x / tg.hblocks_per_win;
-    const int rb = blockIdx.x - b_local * tg.hblocks_per_win;
-    const int b = tg.win0 + b_local;
     const int r0 = rb * HR;                 // first window column x of this block
     const int nrows = min(HR, g.n2 - r0);
     // stage: nrows × NA f2, coalesced
@@ -275,9 +284,25 @@ __global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, con
     peak_wave_reduce(pk);
     if (lane == 0) { sval[wave] = pk.best; sidx[wave] = pk.idx; ssec[wave] = pk.second; }
     __syncthreads();
+    if (tid == 0)
+        for (int w = 1; w < NW; ++w) peak_merge(pk, sval[w], sidx[w], ssec[w]);
+    __syncthreads();
+    return pk;
+}
+
+template <int P, int U, bool RESP, int HR = HP_ROWS, bool FIN = false>
+__global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, const f2 *__restrict__ taps_col)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const LaunchGeo &g = tg.g;
+    const int L = g.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b_local = blockIdx.x / tg.hblocks_per_win;
+    const int rb = blockIdx.x - b_local * tg.hblocks_per_win;
+    const int b = tg.win0 + b_local;
+    Peak pk = hpass_block<P, U, RESP, HR>(tg, taps_col, smem, b_local, rb, b);
     __shared__ int s_last;
     if (tid == 0) {
-        for (int w = 1; w < NW; ++w) peak_merge(pk, sval[w], sidx[w], ssec[w]);
         if (FIN) {
             __hip_atomic_store(&g.part_val[b * g.nslots + rb], pk.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&g.part_idx[b * g.nslots + rb], pk.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -11,6 +11,7 @@
 #include "dog_twopass.hpp"
 #include "dog_fused.hpp"
 #include "dog_exact.hpp"
+#include "dog_coop.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -57,6 +58,7 @@ struct Switches {
     bool host_copy = false, host_sync = false, host_trace = false, twopass_4l = false, hpass16 = false;
     bool ingest_no_nt = false, ingest_trace = false, fused_diag = false;
     bool no_exact = false;                // PDOG_NO_EXACT: trackers start with exact mode off (A/B of its cost)
+    bool no_coop = false;                 // PDOG_NO_COOP: single-clip chains of large windows by stream-ordered launches (A/B)
     size_t scratch_cap = (size_t)6 << 30; // HBM scratch of the two-pass intermediate; larger batches go in chunks
     int fused_pr = 0, fused_pc = 0;       // PDOG_FUSED_P=pr,pc (0: chosen per geometry)
     int host_threads = 0;                 // PDOG_HOST_THREADS (0: min(16, cores))
@@ -76,6 +78,7 @@ Switches read_switches()
     w.ingest_trace = on("PDOG_INGEST_TRACE");
     w.fused_diag = on("PDOG_FUSED_DIAG");
     w.no_exact = on("PDOG_NO_EXACT");
+    w.no_coop = on("PDOG_NO_COOP");
     if (const char *e = std::getenv("PDOG_SCRATCH_MB")) w.scratch_cap = (size_t)std::max(1, std::atoi(e)) << 20;
     if (const char *e = std::getenv("PDOG_FUSED_P")) {
         int a = 0, b = 0;
@@ -227,6 +230,8 @@ struct pdog_tracker {
     bool fused_ok = false;         // the window's tile fits in LDS: the fused kernel takes small batches and short chains
     int hp_rows = HP_ROWS;         // RT rows (window columns) per column-pass workgroup: 16 (P = 13) or 8 (P = 7)
     int32_t *d_chain_tmp = nullptr; // [2][n_clips][2]: current guesses / step results of multi-clip chains
+    int *d_coop_cur = nullptr;     // [2] current guess of the cooperative single-clip chain
+    int coop_grid = -1;            // workgroups of the cooperative chain kernel (0: not available for this tracker; -1: not determined yet)
     int chain_tmp_cap = 0;
     // two-pass path scratch
     f2 *d_V = nullptr;
@@ -959,6 +964,7 @@ int pdog_destroy(pdog_tracker *t)
     if (t->d_dc) (void)hipFree(t->d_dc);
     if (t->d_counter) (void)hipFree(t->d_counter);
     if (t->d_chain_tmp) (void)hipFree(t->d_chain_tmp);
+    if (t->d_coop_cur) (void)hipFree(t->d_coop_cur);
     if (t->h2d_stream) { (void)hipStreamSynchronize(t->h2d_stream); (void)hipStreamDestroy(t->h2d_stream); }
     for (int k = 0; k < pdog_tracker::kIngestSlots; ++k) {
         if (t->h_stage[k]) (void)hipHostFree(t->h_stage[k]);
@@ -1433,6 +1439,89 @@ extern "C" int pdog_detect_batch_host(pdog_tracker *t, const uint8_t *h_frames, 
 
 namespace {
 
+// One cooperative launch for a single clip whose window does not fit the fused kernel (dog_coop.hpp).  Returns
+// PDOG_OK with *launched = false when the path is not available (exact reasons: no cooperative-launch support, the
+// column-pass tile does not fit LDS, the runtime refused the launch) — the caller then falls back to stream-ordered launches.
+int launch_coop_chain(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride, int n_frames,
+                      const int32_t *d_start, int32_t *out_ij, int32_t *progress, bool *launched)
+{
+    *launched = false;
+    if (!t->small_twopass || t->coop_grid == 0 || t->sw.no_coop) return PDOG_OK;
+    const int hr = COOP_HR;
+    const int NA = t->n1 + t->L - 1;
+    const int h1blocks = (NA + HP_ROWS - 1) / HP_ROWS, hblocks = (t->n2 + hr - 1) / hr;
+    const int pitchA = twopass_pitch(t->n2, t->L), pitchV = twopass_pitch(t->n1, t->L, hr);
+    const int NAc = NA;
+    // the refinement's scratch is this kernel's LDS: widest block that fits what the passes need anyway
+    const size_t l1 = (size_t)HP_ROWS * pitchA * sizeof(float), l2 = (size_t)hr * pitchV * sizeof(f2);
+    const size_t base = std::max({l1, l2, refine_lds_bytes(t->n1, t->L, 1, 8)});
+    int ref_cbw = 1, ref_rows = 8;
+    for (int cbw = std::min(t->n2, t->ref_cbw); cbw >= 1; --cbw) {
+        const size_t fixed_r = refine_lds_bytes(t->n1, t->L, cbw, 0);
+        if (fixed_r + (size_t)8 * refine_tile_pitch(cbw, t->L) > base) continue;
+        ref_cbw = cbw;
+        ref_rows = (int)std::min<size_t>((size_t)NAc, (base - fixed_r) / (size_t)refine_tile_pitch(cbw, t->L));
+        while (ref_rows > 8 && refine_lds_bytes(t->n1, t->L, cbw, ref_rows) > base) --ref_rows;
+        break;
+    }
+    if (base > kMaxLds - 1024) { t->coop_grid = 0; return PDOG_OK; }
+    if (t->coop_grid < 0) {
+        int coop = 0;
+        if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, t->device) != hipSuccess || !coop) { t->coop_grid = 0; return PDOG_OK; }
+        if (int rc = raise_lds_limit((const void *)dog_coop_chain_kernel, base)) return rc;
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)dog_coop_chain_kernel, 256, base) != hipSuccess || per_cu < 1 ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) != hipSuccess) { t->coop_grid = 0; return PDOG_OK; }
+        t->coop_grid = std::max(1, std::min(std::max(h1blocks, hblocks), per_cu * cus));
+    }
+    const size_t per_win = (size_t)t->n2 * NA * sizeof(f2);
+    if (t->v_bytes < per_win || t->cap_windows < 1 || !t->d_coop_cur) {
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        if (t->v_bytes < per_win) {
+            if (t->d_V) (void)hipFree(t->d_V);
+            t->d_V = nullptr; t->v_bytes = 0;
+            HIP_TRY(hipMalloc(&t->d_V, per_win));
+            t->v_bytes = per_win;
+        }
+        if (t->cap_windows < 1) { if (int rc = ensure_capacity(t, 1)) return rc; }
+        if (!t->d_coop_cur) HIP_TRY(hipMalloc(&t->d_coop_cur, sizeof(int) * 2));
+    }
+    CoopGeo cg;
+    std::memset(&cg, 0, sizeof cg);
+    LaunchGeo &g = cg.tg.g;
+    g.frames = d_frames;
+    g.frame_stride = frame_stride;
+    g.row_stride = row_stride;
+    g.part_val = t->d_part_val;
+    g.part_idx = t->d_part_idx;
+    g.part_sec = t->d_part_sec;
+    g.part_mask = t->d_part_mask;
+    g.ex = exact_ctl(t);
+    g.fh = t->fh; g.fw = t->fw; g.r1 = t->r1; g.r2 = t->r2; g.n1 = t->n1; g.n2 = t->n2;
+    g.L = t->L; g.fill = t->fill; g.nstrips = hblocks; g.nslots = hblocks; g.n = 1; g.nblocks = hblocks;
+    cg.tg.RT = t->d_V;
+    cg.tg.TWin = t->n2 + t->L - 1;
+    cg.tg.NA = NA;
+    cg.tg.h1blocks_per_win = h1blocks;
+    cg.tg.hblocks_per_win = hblocks;
+    cg.tg.pitchA = pitchA;
+    cg.tg.pitchV = pitchV;
+    cg.n_frames = n_frames;
+    cg.start = d_start;
+    cg.out_ij = out_ij;
+    cg.cur = t->d_coop_cur;
+    cg.rp = t->exact ? t->d_rp : nullptr;
+    cg.ref_cbw = ref_cbw;
+    cg.ref_rows = ref_rows;
+    cg.progress = progress;
+    const f2 *tr = t->d_taps_row, *tc = t->d_taps_col;
+    void *args[] = {(void *)&cg, (void *)&tr, (void *)&tc};
+    const hipError_t e = hipLaunchCooperativeKernel((const void *)dog_coop_chain_kernel, dim3(t->coop_grid), dim3(256), args, (unsigned)base, t->stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); t->coop_grid = 0; return PDOG_OK; } // refused: stream-ordered launches instead
+    *launched = true;
+    return PDOG_OK;
+}
+
 // stream-ordered fallback: frame k's guess is frame k-1's (clamped) answer, read straight from the
 // output array — stream order is the dependency, no host round trip per frame
 int chain_by_launches(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
@@ -1508,8 +1597,17 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
         int rc = ensure_capacity(t, n_clips);
         if (rc) return rc;
     }
-    if (n_clips == 1) // stream order is the dependency: frame k's guess is read straight from frame k-1's answer
+    if (n_clips == 1) {
+        // one cooperative launch for the clip where it is available (windows beyond the fused kernel, any kernel the
+        // two-pass path serves) …
+        if (!t->forced_variant || t->var->twopass) {
+            bool launched = false;
+            if (int rc = launch_coop_chain(t, d_frames, frame_stride, row_stride, n_frames, d_start_guesses, d_out_ij, nullptr, &launched)) return rc;
+            if (launched) return PDOG_OK;
+        }
+        // … else stream order is the dependency: frame k's guess is read straight from frame k-1's answer
         return chain_by_launches(t, d_frames, frame_stride, row_stride, n_frames, d_start_guesses, d_out_ij);
+    }
     if (t->chain_tmp_cap < n_clips) {
         HIP_TRY(hipStreamSynchronize(t->stream));
         if (t->d_chain_tmp) (void)hipFree(t->d_chain_tmp);
@@ -1577,6 +1675,11 @@ extern "C" int pdog_detect_chain_progress(pdog_tracker *t, const uint8_t *d_fram
     if (t->cap_windows < 1) {
         HIP_TRY(hipStreamSynchronize(t->stream));
         if (int rc = ensure_capacity(t, 1)) return rc;
+    }
+    if (!t->forced_variant || t->var->twopass) { // one cooperative launch: workgroup 0 publishes k + 1 after every frame
+        bool launched = false;
+        if (int rc = launch_coop_chain(t, d_frames, frame_stride, row_stride, n_frames, t->d_small, d_out, d_prog, &launched)) return rc;
+        if (launched) return PDOG_OK;
     }
     for (int k = 0; k < n_frames; ++k) { // stream-ordered launches per frame; frame k's guess is read from the (host-mapped) answer k − 1
         bool armed = false;

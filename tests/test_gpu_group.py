@@ -195,3 +195,47 @@ def test_switches_are_read_once_at_create(pt, oracle, monkeypatch):
     g = (int(guesses[0, 0]), int(guesses[0, 1]))
     assert t1(g) == t2(g)
     t1.close(); t2.close()
+
+
+def test_cooperative_single_clip_chain(pt, oracle, monkeypatch):
+    """A single clip whose window does not fit the fused kernel runs as ONE cooperative launch (csrc/dog_coop.hpp: resident
+    workgroups, grid barriers between row pass, column pass and the finishing step) — positions equal to the oracle's
+    serial chain (src/PawsomeTracker.jl:163-169, :167) and to the stream-ordered-launch fallback (PDOG_NO_COOP), with the
+    refinement forced on every frame too, and through the progress-publishing form."""
+    import torch
+    from oracle import synth
+    from oracle.dog_oracle import OracleTracker
+    for tw, ws, fh, fw, nf in ((25, (256, 256), 400, 520, 10), (120, (205, 205), 420, 500, 4), (41, (130, 190), 300, 400, 6)):
+        radii = (ws[0] // 2, ws[1] // 2)
+        rng = np.random.default_rng(int(tw))
+        centres = np.cumsum(rng.integers(-6, 7, (nf, 2)), 0) + np.array([fh // 2, fw // 2])
+        clip = np.stack([synth.disc_frame(fh, fw, (int(c[0]), int(c[1])), tw, True) for c in centres])
+        clip = np.clip(clip.astype(np.int16) + rng.integers(-3, 4, clip.shape), 0, 255).astype(np.uint8)
+        start = (int(centres[0, 0]) + 5, int(centres[0, 1]) - 7)
+        ot = OracleTracker(clip[0], tw, ws, True, oracle)
+        want, g = [], start
+        for k in range(nf):
+            ot.data[...] = clip[k]
+            g = ot(g)
+            want.append(list(g))
+        d_clip = torch.from_numpy(clip).cuda()
+        for exact in (1, 2):
+            if exact == 2 and tw == 120:
+                continue                         # every pixel through the dense chain at l = 293: minutes
+            bt = pt.BatchTracker(fh, fw, tw, ws, True, ot.fill)
+            bt.set_exact(exact)
+            assert bt.kernel_for_batch(1) == 200          # too large for the fused kernel: the two-pass family
+            got = bt.detect_chain(d_clip, start)
+            bt.sync()
+            assert got.cpu().numpy().tolist() == want, (tw, exact)
+            cp = bt.detect_chain_progress(d_clip, start)
+            assert cp.wait().tolist() == want and cp.done() == nf
+            cp.close()
+            bt.close()
+        monkeypatch.setenv("PDOG_NO_COOP", "1")
+        bt = pt.BatchTracker(fh, fw, tw, ws, True, ot.fill)
+        got = bt.detect_chain(d_clip, start)
+        bt.sync()
+        assert got.cpu().numpy().tolist() == want, (tw, "launches")
+        bt.close()
+        monkeypatch.delenv("PDOG_NO_COOP")
