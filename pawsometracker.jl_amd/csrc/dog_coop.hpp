@@ -13,7 +13,6 @@
 #pragma once
 #include "dog_twopass.hpp"
 #include "dog_exact.hpp"
-#include <hip/hip_cooperative_groups.h>
 
 namespace pdog {
 
@@ -26,41 +25,54 @@ struct CoopGeo {
     const RefineParams *rp;  // exact mode's constants (null = off)
     int ref_cbw, ref_rows;   // refinement: window columns per block; resident tile rows (its scratch is this kernel's LDS)
     int32_t *progress;       // NULL, or a host-coherent word that receives k + 1 after frame k (system-scope release)
+    unsigned *sync;          // device, 3 words zeroed before the launch: barrier arrivals, column-pass arrivals, frame flag
 };
 
 constexpr int COOP_HR = 8; // window columns per column-pass block (as the two-pass kernels' 8-row form)
 
+// Grid barrier for workgroups the cooperative launch keeps resident: a monotonic arrival counter (zeroed by the host
+// before the launch), release on arrival, acquire spin until everyone of this round has arrived.  (HIP's
+// cooperative_groups grid sync measured ≈12 µs per barrier here — more than the three launches it was to replace.)
+__device__ __forceinline__ void coop_barrier(unsigned *ctr, unsigned target)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+
 static __global__ __launch_bounds__(256) void dog_coop_chain_kernel(const CoopGeo cg, const f2 *__restrict__ taps_row,
                                                                     const f2 *__restrict__ taps_col)
 {
-    namespace cgns = cooperative_groups;
-    cgns::grid_group grid = cgns::this_grid();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_refine;
+    __shared__ int s_refine, s_last;
     __shared__ float s_max;
     const TwoPassGeo &tg = cg.tg;
     const LaunchGeo &g = tg.g;
     const int tid = threadIdx.x;
+    const unsigned G = gridDim.x;
+    unsigned *const bar = cg.sync, *const arrive = cg.sync + 1, *const flag = cg.sync + 2;
     for (int k = 0; k < cg.n_frames; ++k) {
         int g1, g2;
         if (k == 0) {
             g1 = cg.start[0];
             g2 = cg.start[1];
-        } else { // written by workgroup 0 before the last grid barrier
+        } else { // written by the finishing workgroup of frame k − 1 before it released the frame flag
             g1 = __hip_atomic_load(&cg.cur[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             g2 = __hip_atomic_load(&cg.cur[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const uint8_t *__restrict__ frame = g.frames + (long long)k * g.frame_stride;
         // ---- row pass → RT (global scratch, transposed) ----
-        for (int rb = blockIdx.x; rb < tg.h1blocks_per_win; rb += gridDim.x) {
+        for (int rb = blockIdx.x; rb < tg.h1blocks_per_win; rb += G) {
             h1_block<13, 8, true>(tg, taps_row, smem, 0, rb, frame, g1, g2, 0);
             __syncthreads(); // the LDS tile is rewritten by the next block
         }
         __threadfence();
-        grid.sync();
-        __threadfence(); // RT written by other CUs: nothing stale from the previous frame in this CU's cache
+        coop_barrier(bar, (unsigned)(k + 1) * G); // every RT row is there (and nothing stale of frame k − 1 in this CU's cache)
         // ---- column pass + partial peaks ----
-        for (int cb = blockIdx.x; cb < tg.hblocks_per_win; cb += gridDim.x) {
+        for (int cb = blockIdx.x; cb < tg.hblocks_per_win; cb += G) {
             const Peak pk = hpass_block<7, 16, false, COOP_HR>(tg, taps_col, smem, 0, cb, 0);
             if (tid == 0) {
                 __hip_atomic_store(&g.part_val[cb], pk.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -68,11 +80,13 @@ static __global__ __launch_bounds__(256) void dog_coop_chain_kernel(const CoopGe
                 __hip_atomic_store(&g.part_sec[cb], pk.second, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        __threadfence();
-        grid.sync();
-        __threadfence();
-        // ---- workgroup 0: combine, clamp, refine, publish the next guess ----
-        if (blockIdx.x == 0) {
+        // ---- the workgroup that arrives last combines, clamps, refines and releases the frame; the others wait for it ----
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old == (unsigned)(k + 1) * G - 1u);
+        }
+        __syncthreads();
+        if (s_last) {
             if (tid < 64) {
                 Peak pk;
                 peak_init(pk);
@@ -128,11 +142,12 @@ static __global__ __launch_bounds__(256) void dog_coop_chain_kernel(const CoopGe
                     __threadfence_system();
                     __hip_atomic_store(cg.progress, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
+                __hip_atomic_store(flag, (unsigned)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); // the next guess is out
             }
+        } else if (tid == 0) {
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(k + 1)) __builtin_amdgcn_s_sleep(1);
         }
-        __threadfence();
-        grid.sync();
-        __threadfence();
+        __syncthreads();
     }
 }
 

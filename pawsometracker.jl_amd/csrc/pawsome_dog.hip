@@ -230,7 +230,7 @@ struct pdog_tracker {
     bool fused_ok = false;         // the window's tile fits in LDS: the fused kernel takes small batches and short chains
     int hp_rows = HP_ROWS;         // RT rows (window columns) per column-pass workgroup: 16 (P = 13) or 8 (P = 7)
     int32_t *d_chain_tmp = nullptr; // [2][n_clips][2]: current guesses / step results of multi-clip chains
-    int *d_coop_cur = nullptr;     // [2] current guess of the cooperative single-clip chain
+    int *d_coop_cur = nullptr;     // [2] current guess of the cooperative single-clip chain, then 3 words of barrier state
     int coop_grid = -1;            // workgroups of the cooperative chain kernel (0: not available for this tracker; -1: not determined yet)
     int chain_tmp_cap = 0;
     // two-pass path scratch
@@ -1484,7 +1484,7 @@ int launch_coop_chain(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_st
             t->v_bytes = per_win;
         }
         if (t->cap_windows < 1) { if (int rc = ensure_capacity(t, 1)) return rc; }
-        if (!t->d_coop_cur) HIP_TRY(hipMalloc(&t->d_coop_cur, sizeof(int) * 2));
+        if (!t->d_coop_cur) HIP_TRY(hipMalloc(&t->d_coop_cur, sizeof(int) * 8));
     }
     CoopGeo cg;
     std::memset(&cg, 0, sizeof cg);
@@ -1514,6 +1514,8 @@ int launch_coop_chain(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_st
     cg.ref_cbw = ref_cbw;
     cg.ref_rows = ref_rows;
     cg.progress = progress;
+    cg.sync = reinterpret_cast<unsigned *>(t->d_coop_cur + 4);
+    HIP_TRY(hipMemsetAsync(t->d_coop_cur + 4, 0, sizeof(unsigned) * 4, t->stream));
     const f2 *tr = t->d_taps_row, *tc = t->d_taps_col;
     void *args[] = {(void *)&cg, (void *)&tr, (void *)&tc};
     const hipError_t e = hipLaunchCooperativeKernel((const void *)dog_coop_chain_kernel, dim3(t->coop_grid), dim3(256), args, (unsigned)base, t->stream);
