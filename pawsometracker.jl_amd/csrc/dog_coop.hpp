@@ -10,6 +10,11 @@
 //     column pass + partial peaks (hpass_block)                            → grid barrier
 //     workgroup 0: combine, clamp (:58-61), exact-mode refinement, next guess → grid barrier
 // Same arithmetic as the two-pass kernels (same block functions), same finishing logic as dog_finish_kernel.
+//
+// MEASURED (1080p, 257×257 window, MI355X): 48 µs per frame with cooperative_groups' grid sync, 31 µs with the barriers
+// below, against 27.6 µs for the three stream-ordered launches — a frame's critical path is ≈12 dependent memory round
+// trips (tile → RT → partials → guess → DC samples …), not launch gaps, and the launches overlap their own set-up with
+// the previous kernel's tail.  The path is therefore OPT-IN (PDOG_COOP=1) and kept for the record and for its test.
 #pragma once
 #include "dog_twopass.hpp"
 #include "dog_exact.hpp"

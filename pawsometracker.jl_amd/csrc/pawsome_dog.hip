@@ -58,7 +58,8 @@ struct Switches {
     bool host_copy = false, host_sync = false, host_trace = false, twopass_4l = false, hpass16 = false;
     bool ingest_no_nt = false, ingest_trace = false, fused_diag = false;
     bool no_exact = false;                // PDOG_NO_EXACT: trackers start with exact mode off (A/B of its cost)
-    bool no_coop = false;                 // PDOG_NO_COOP: single-clip chains of large windows by stream-ordered launches (A/B)
+    bool coop = false;                    // PDOG_COOP: single-clip chains of large windows as ONE cooperative launch (dog_coop.hpp; measured slower
+                                          // than the three stream-ordered launches per frame it replaces, so off by default)
     size_t scratch_cap = (size_t)6 << 30; // HBM scratch of the two-pass intermediate; larger batches go in chunks
     int fused_pr = 0, fused_pc = 0;       // PDOG_FUSED_P=pr,pc (0: chosen per geometry)
     int host_threads = 0;                 // PDOG_HOST_THREADS (0: min(16, cores))
@@ -78,7 +79,7 @@ Switches read_switches()
     w.ingest_trace = on("PDOG_INGEST_TRACE");
     w.fused_diag = on("PDOG_FUSED_DIAG");
     w.no_exact = on("PDOG_NO_EXACT");
-    w.no_coop = on("PDOG_NO_COOP");
+    w.coop = on("PDOG_COOP");
     if (const char *e = std::getenv("PDOG_SCRATCH_MB")) w.scratch_cap = (size_t)std::max(1, std::atoi(e)) << 20;
     if (const char *e = std::getenv("PDOG_FUSED_P")) {
         int a = 0, b = 0;
@@ -1446,7 +1447,7 @@ int launch_coop_chain(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_st
                       const int32_t *d_start, int32_t *out_ij, int32_t *progress, bool *launched)
 {
     *launched = false;
-    if (!t->small_twopass || t->coop_grid == 0 || t->sw.no_coop) return PDOG_OK;
+    if (!t->small_twopass || t->coop_grid == 0 || !t->sw.coop) return PDOG_OK;
     const int hr = COOP_HR;
     const int NA = t->n1 + t->L - 1;
     const int h1blocks = (NA + HP_ROWS - 1) / HP_ROWS, hblocks = (t->n2 + hr - 1) / hr;

@@ -198,10 +198,11 @@ def test_switches_are_read_once_at_create(pt, oracle, monkeypatch):
 
 
 def test_cooperative_single_clip_chain(pt, oracle, monkeypatch):
-    """A single clip whose window does not fit the fused kernel runs as ONE cooperative launch (csrc/dog_coop.hpp: resident
-    workgroups, grid barriers between row pass, column pass and the finishing step) — positions equal to the oracle's
-    serial chain (src/PawsomeTracker.jl:163-169, :167) and to the stream-ordered-launch fallback (PDOG_NO_COOP), with the
-    refinement forced on every frame too, and through the progress-publishing form."""
+    """A single clip whose window does not fit the fused kernel as ONE cooperative launch (csrc/dog_coop.hpp: resident
+    workgroups, grid barriers between row pass, column pass and the finishing step; opt-in with PDOG_COOP=1 because it
+    measured slower than the launches it replaces) — positions equal to the oracle's serial chain
+    (src/PawsomeTracker.jl:163-169, :167) and to the default stream-ordered launches, with the refinement forced on every
+    frame too, and through the progress-publishing form."""
     import torch
     from oracle import synth
     from oracle.dog_oracle import OracleTracker
@@ -219,6 +220,7 @@ def test_cooperative_single_clip_chain(pt, oracle, monkeypatch):
             g = ot(g)
             want.append(list(g))
         d_clip = torch.from_numpy(clip).cuda()
+        monkeypatch.setenv("PDOG_COOP", "1")
         for exact in (1, 2):
             if exact == 2 and tw == 120:
                 continue                         # every pixel through the dense chain at l = 293: minutes
@@ -232,10 +234,9 @@ def test_cooperative_single_clip_chain(pt, oracle, monkeypatch):
             assert cp.wait().tolist() == want and cp.done() == nf
             cp.close()
             bt.close()
-        monkeypatch.setenv("PDOG_NO_COOP", "1")
+        monkeypatch.delenv("PDOG_COOP")
         bt = pt.BatchTracker(fh, fw, tw, ws, True, ot.fill)
         got = bt.detect_chain(d_clip, start)
         bt.sync()
         assert got.cpu().numpy().tolist() == want, (tw, "launches")
         bt.close()
-        monkeypatch.delenv("PDOG_NO_COOP")
