@@ -141,6 +141,23 @@ def cpu_baseline(frames_host, guesses_host, fill, tw, radii, budget_s=8.0):
             "within": (within, n_w), "across": (across, n_a), "separable": (sep, n_s)}
 
 
+class native_stdout_to_stderr:
+    """RCCL prints a version banner on the process's stdout when a communicator is created; the contract is ONE JSON
+    line there.  While this is active, file descriptor 1 points at stderr (native code included)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,7 +257,8 @@ def run_group(args):
         guesses.append(torch.from_numpy(g_h).to(dev))
         guesses_h.append(g_h)
         centres.append(c)
-    gt = pt.GroupTracker(list(range(world)), fh, fw, tw, ws, True, fill)
+    with native_stdout_to_stderr():
+        gt = pt.GroupTracker(list(range(world)), fh, fw, tw, ws, True, fill)
     assert all(gt.shard(n_total, r) == (r * batch, (r + 1) * batch) for r in range(world))
     gt.reserve(n_total)
     info = gt.info(0)
@@ -249,9 +267,10 @@ def run_group(args):
     root_stream = torch.cuda.ExternalStream(gt.stream(0), device=0)
     for r in range(world):
         torch.cuda.synchronize(r)
-    for _ in range(args.warmup):
-        gt.detect(frames, guesses, n_total, out)
-    gt.sync()
+    with native_stdout_to_stderr():
+        for _ in range(args.warmup):
+            gt.detect(frames, guesses, n_total, out)
+        gt.sync()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for r in range(world):
         torch.cuda.synchronize(r)
@@ -314,10 +333,11 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        with native_stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
 
     fh, fw, tw, ws, batch, desc = WORKLOADS[args.workload]
     if args.batch:
@@ -347,10 +367,12 @@ def main():
             return pt.gather_positions(out, n_total)
         return out
 
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        pt.gather_positions(out, n_total)   # RCCL sets up its point-to-point channels on first use: not part of any timed step
+    with native_stdout_to_stderr():
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            pt.gather_positions(out, n_total)   # RCCL sets up its point-to-point channels on first use: not part of any timed step
+            torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
     refined0 = bt.exact_stats()[2]
