@@ -38,8 +38,10 @@ namespace pdog {
     extern template __global__ void dog_chain_kernel<LT>(const ChainGeo, const f2 *, const f2 *);
 #include "roll_lengths.def"
 #undef PDOG_ROLL_L
-extern template __global__ void dog_roll_kernel<65, false, 0, 10>(const LaunchGeo, const f2 *, const f2 *);
-extern template __global__ void dog_roll_kernel<65, false, 0, 2>(const LaunchGeo, const f2 *, const f2 *);
+#define PDOG_EPI_CLASSES(X) X(10) X(2) X(16) X(14) X(6) X(4) // roll_inst.hip: window sizes 256, 512, 64, 128, 384, 1024
+#define PDOG_EPI_DECL(C) extern template __global__ void dog_roll_kernel<65, false, 0, C>(const LaunchGeo, const f2 *, const f2 *);
+PDOG_EPI_CLASSES(PDOG_EPI_DECL)
+#undef PDOG_EPI_DECL
 } // namespace pdog
 
 namespace {
@@ -723,8 +725,9 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     kernel_fn fn = d_out_resp ? v.fn_resp : v.fn;
     if (!d_out_resp && v.roll && v.LT == 65 && v.id == 100) { // instances with statically shortened epilogue bodies for the common window heights
         const int cls = roll_epi_class(t->n1, 65);
-        if (cls == 10) fn = (kernel_fn)dog_roll_kernel<65, false, 0, 10>;
-        else if (cls == 2) fn = (kernel_fn)dog_roll_kernel<65, false, 0, 2>;
+#define PDOG_EPI_PICK(C) if (cls == C) fn = (kernel_fn)dog_roll_kernel<65, false, 0, C>;
+        PDOG_EPI_CLASSES(PDOG_EPI_PICK)
+#undef PDOG_EPI_PICK
     }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(v.NT), lds_bytes, t->stream, g,
                        (const f2 *)t->d_taps_row, (const f2 *)(v.roll ? t->d_taps_roll : t->d_taps_col));

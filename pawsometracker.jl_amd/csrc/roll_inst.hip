@@ -14,10 +14,18 @@ namespace pdog {
     template __global__ void dog_chain_kernel<LT>(const ChainGeo, const f2 *, const f2 *);
 #include "roll_lengths.def"
 #undef PDOG_ROLL_L
-#if PDOG_ROLL_SET == 9
 // l = 65 (target_width 25, the reference default) for the window-height classes of the common window sizes
-// (roll_epi_class: 256 → 257 rows = class 10, 512 → 513 rows = class 2): statically shortened epilogue bodies
-template __global__ void dog_roll_kernel<65, false, 0, 10>(const LaunchGeo, const f2 *, const f2 *);
-template __global__ void dog_roll_kernel<65, false, 0, 2>(const LaunchGeo, const f2 *, const f2 *);
+// (roll_epi_class = ((n1 + 2) ÷ 4) mod 18): statically shortened epilogue bodies.  window_size → rows → class:
+// 64 → 65 → 16, 128 → 129 → 14, 256 → 257 → 10, 384 → 385 → 6, 512 → 513 → 2, 1024 → 1025 → 4.
+#define PDOG_EPI_INST(C) template __global__ void dog_roll_kernel<65, false, 0, C>(const LaunchGeo, const f2 *, const f2 *);
+#if PDOG_ROLL_SET == 9
+PDOG_EPI_INST(10) PDOG_EPI_INST(2)
 #endif
+#if PDOG_ROLL_SET == 10
+PDOG_EPI_INST(16) PDOG_EPI_INST(14)
+#endif
+#if PDOG_ROLL_SET == 11
+PDOG_EPI_INST(6) PDOG_EPI_INST(4)
+#endif
+#undef PDOG_EPI_INST
 } // namespace pdog

@@ -915,3 +915,32 @@ def test_every_roll_instance_pinned(pt, oracle, l):
                     g = ot(g)
                     assert tuple(int(v) for v in out[c][k]) == g, (l, c, k)
         bt.close()
+
+
+@pytest.mark.parametrize("win_h", [64, 128, 256, 384, 512, 1024, 100])
+def test_epilogue_height_classes(pt, oracle, win_h):
+    """dog_roll_kernel<65, false, 0, EPI>: instances with statically shortened epilogue bodies for the window-height
+    classes of the common window sizes (64 … 1024 rows; 100 = a height without an instance → the full bodies).  The
+    target sits in the LAST rows of the window, where the shortened bodies run; positions against the dense oracle."""
+    import torch
+    from oracle import synth
+    tw, ws = 25, (win_h, 70)
+    radii = (ws[0] // 2, ws[1] // 2)
+    n, fh, fw = 12, max(160, win_h + 40), 200
+    rng = np.random.default_rng(win_h)
+    guesses = np.stack([rng.integers(fh // 2 - 10, fh // 2 + 10, n), rng.integers(60, 140, n)], 1).astype(np.int32)
+    frames = np.empty((n, fh, fw), np.uint8)
+    for b in range(n):      # disc centre in the bottom 40 rows of the window (clipped by the frame for the tallest windows)
+        ci = int(min(fh, guesses[b, 0] + radii[0] - rng.integers(0, 40)))
+        synth.disc_frame(fh, fw, (ci, int(guesses[b, 1] + rng.integers(-20, 21))), tw, True, out=frames[b])
+    frames = np.clip(frames.astype(np.int16) + rng.integers(-3, 4, frames.shape), 0, 255).astype(np.uint8)
+    fill = oracle.mode_u8(frames[0])
+    K = oracle.dog_kernel(oracle.sigma(tw), True)
+    ref = oracle.detect_batch(frames, fill, K, radii, guesses)
+    bt = pt.BatchTracker(fh, fw, tw, ws, True, fill)
+    bt.set_variant(100)
+    assert bt.kernel_for_batch(n) == 100
+    got = bt.detect(torch.from_numpy(frames).cuda(), torch.from_numpy(guesses).cuda())
+    bt.sync()
+    assert np.array_equal(got.cpu().numpy(), ref), win_h
+    bt.close()
