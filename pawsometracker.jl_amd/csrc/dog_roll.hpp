@@ -608,6 +608,9 @@ static __global__ void dog_chain_step_kernel(const int *__restrict__ step_ij, in
     cur[2 * c + 1] = j;
 }
 
+// dynamic LDS of dog_thin_kernel: the R column (f2 per input row) and the column's input patch as bytes
+__host__ __device__ constexpr size_t thin_lds_bytes(int n1, int L) { return ((size_t)(n1 + L - 1) * sizeof(f2) + 15) / 16 * 16 + (size_t)(n1 + L - 1) * ((L + 3) / 4 * 4); }
+
 // ---- thin remainder ----
 // A window whose width is 64·k + r with small r (257 = 4·64 + 1) would need a whole extra strip for
 // r columns.  Instead those columns are done here, one 256-thread workgroup per (window, column):
@@ -652,37 +655,55 @@ __global__ __launch_bounds__(256) void dog_thin_kernel(const LaunchGeo g, const 
     }
     const float fdc = (float)dc;
 
-    // ---- row pass: R[a] for input rows a = tid, tid + 256, … ----
+    // ---- the column's input patch, NA rows × l pixels, → LDS bytes: a dword per item, loaded unconditionally at an
+    // address clamped into the frame (a clamped dword still holds every in-frame byte its item needs, at a shifted
+    // position), PaddedView fill (:48) selected afterwards — coalesced along the rows, no per-pixel branches (the old
+    // row pass read its own row straight from memory, 64 cache lines per load instruction, and its border path spilled
+    // 360 SGPRs) ----
+    constexpr int TP = (L + 3) / 4 * 4, TQ = TP / 4;  // tile pitch in bytes / dwords
+    uint8_t *tile = smem + ((size_t)NA * sizeof(f2) + 15) / 16 * 16;
     const int gj0 = wj0 + x; // frame col of input k = 0
+    if (g.fw >= 4) {
+#pragma unroll 4
+        for (int e = tid; e < NA * TQ; e += NT) {
+            const int a = e / TQ, q = e - a * TQ;
+            const int gi = ti0 + a, gj = gj0 + 4 * q;
+            const int gjc = min(max(gj, 0), g.fw - 4);
+            uint32_t w;
+            __builtin_memcpy(&w, frame + (long long)min(max(gi, 0), g.fh - 1) * g.row_stride + gjc, 4);
+            const bool rowok = gi >= 0 && gi < g.fh;
+            uint32_t o = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gjj = gj + i;
+                const uint32_t px = (rowok && gjj >= 0 && gjj < g.fw) ? ((w >> (8 * ((gjj - gjc) & 3))) & 0xffu) : (uint32_t)g.fill;
+                o |= px << (8 * i);
+            }
+            *reinterpret_cast<uint32_t *>(tile + a * TP + 4 * q) = o;
+        }
+    } else {
+        for (int e = tid; e < NA * TP; e += NT) {
+            const int a = e / TP, cc = e - a * TP;
+            const int gi = ti0 + a, gj = gj0 + cc;
+            tile[e] = (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) ? frame[(long long)gi * g.row_stride + gj] : (uint8_t)g.fill;
+        }
+    }
+    __syncthreads();
+    // ---- row pass: R[a] for input rows a = tid, tid + 256, … (same operation order as the strips: pairs k ascending, centre last) ----
     for (int a = tid; a < NA; a += NT) {
-        const int gi = ti0 + a;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(tile + a * TP);
         float v[L];
-        const bool rowok = gi >= 0 && gi < g.fh;
-        if (rowok && gj0 >= 0 && gj0 + ((L + 3) & ~3) <= g.fw) {
-            const uint8_t *src = frame + (long long)gi * g.row_stride + gj0;
 #pragma unroll
-            for (int q = 0; q < (L + 3) / 4; ++q) {
-                uint32_t w;
-                __builtin_memcpy(&w, src + 4 * q, 4);
+        for (int q = 0; q < TQ; ++q) {
+            const uint32_t w = src[q];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (4 * q + i < L) v[4 * q + i] = (float)((w >> (8 * i)) & 0xffu) - fdc;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < L; ++k) {
-                const int gj = gj0 + k;
-                int p = g.fill;
-                if (rowok && gj >= 0 && gj < g.fw) p = frame[(long long)gi * g.row_stride + gj];
-                v[k] = (float)p - fdc;
-            }
+            for (int i = 0; i < 4; ++i)
+                if (4 * q + i < L) v[4 * q + i] = (float)((w >> (8 * i)) & 0xffu) - fdc;
         }
         f2 acc = f2{0.f, 0.f};
-        // taps in blocks of 8 behind a base pointer re-pinned per block: left to itself the compiler hoists all 33
-        // loop-invariant tap pairs out of the row loop and spills them (400 SGPR spills, half of this kernel's VALU slots)
         tap_ptr tb = trow;
 #pragma unroll
-        for (int k0 = 0; k0 < H; k0 += 8) {
+        for (int k0 = 0; k0 < H; k0 += 8) { // taps in blocks of 8 behind a base pointer re-pinned per block (not hoisted out of the row loop)
             tb = pin_taps(tb);
 #pragma unroll
             for (int k = k0; k < k0 + 8; ++k)

@@ -410,7 +410,7 @@ int choose_variant(pdog_tracker *t, int forced)
     if (best->roll && best->thin && t->n2 > best->tw()) {
         // width = 64·k + r: r ≤ kThinMax columns are cheaper one by one than as an extra strip
         const int r = t->n2 % best->tw();
-        const size_t thin_lds = sizeof(f2) * (size_t)(t->n1 + t->L - 1);
+        const size_t thin_lds = thin_lds_bytes(t->n1, t->L);
         if (r > 0 && r <= kThinMax && thin_lds <= kMaxLds - 1024) {
             for (kernel_fn f : {best->thin, best->thin_resp}) {
                 if (int rc = raise_lds_limit((const void *)f, thin_lds)) return rc;
@@ -709,7 +709,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         // fork: the thin kernel only reads the frames and writes its own partial slots
         HIP_TRY(hipEventRecord(t->ev_fork, t->stream));
         HIP_TRY(hipStreamWaitEvent(t->aux_stream, t->ev_fork, 0));
-        const size_t thin_lds = sizeof(f2) * (size_t)(t->n1 + t->L - 1);
+        const size_t thin_lds = thin_lds_bytes(t->n1, t->L);
         hipLaunchKernelGGL(d_out_resp ? v.thin_resp : v.thin, dim3(n * t->nthin), dim3(256), thin_lds, t->aux_stream, g,
                            (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
         HIP_TRY(hipGetLastError());

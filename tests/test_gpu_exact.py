@@ -92,7 +92,7 @@ def test_hard_window_census_45x45(pt, oracle):
     K = oracle.dog_kernel(sig, True)
     # the reference's arithmetic for EVERY window: dense 65×65 Float64 in kernel column-major order (8.6 M MAC each)
     dense = oracle.detect_batch_par(frames, fill, K, sig, True, radii, guesses, separable=False)
-    for variant in (-1, 300, 100):          # automatic choice, fused (inline refinement), roll + refinement kernel
+    for variant in (-1, 300, 100, 200, 13):  # automatic choice, fused (inline refinement), roll, two-pass, ring + finishing kernel
         got, (on, thr, refined) = _gpu_positions(pt, frames, guesses, tw, ws, fill, True, variant)
         bad = np.flatnonzero((got != dense).any(1))
         assert on and bad.size == 0, (variant, bad.size, fam[bad][:20], got[bad][:5], dense[bad][:5])
