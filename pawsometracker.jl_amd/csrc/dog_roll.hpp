@@ -663,7 +663,15 @@ __global__ __launch_bounds__(256) void dog_thin_kernel(const LaunchGeo g, const 
     constexpr int TP = (L + 3) / 4 * 4, TQ = TP / 4;  // tile pitch in bytes / dwords
     uint8_t *tile = smem + ((size_t)NA * sizeof(f2) + 15) / 16 * 16;
     const int gj0 = wj0 + x; // frame col of input k = 0
-    if (g.fw >= 4) {
+    if (ti0 >= 0 && ti0 + NA <= g.fh && gj0 >= 0 && gj0 + TP <= g.fw) { // the whole patch inside the frame (workgroup-uniform): a plain copy
+#pragma unroll 4
+        for (int e = tid; e < NA * TQ; e += NT) {
+            const int a = e / TQ, q = e - a * TQ;
+            uint32_t w;
+            __builtin_memcpy(&w, frame + (long long)(ti0 + a) * g.row_stride + gj0 + 4 * q, 4);
+            *reinterpret_cast<uint32_t *>(tile + a * TP + 4 * q) = w;
+        }
+    } else if (g.fw >= 4) {
 #pragma unroll 4
         for (int e = tid; e < NA * TQ; e += NT) {
             const int a = e / TQ, q = e - a * TQ;
