@@ -430,9 +430,9 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
 }
 
 // ---- the last kernel of a batch: strip combine + index map + clamp (:58-61), and the refinement of exact mode ----
-// One workgroup per window.  Thread 0 combines the window's partial peaks (a handful of loads), writes the FP32 answer,
-// checks the guess's range and — the usual case — that is all: the runner-up lies further than 2δ below the maximum.
-// Otherwise the workgroup refines the window (above) and writes the reference's answer.
+// Four windows per workgroup: each wave combines one window's partial peaks (a handful of loads), writes the FP32
+// answer, checks the guess's range and — the usual case — that is all: the runner-up lies further than 2δ below the
+// maximum.  Otherwise the whole workgroup refines the window (above) and writes the reference's answer.
 struct FinishGeo {
     LaunchGeo g;                 // frames, strides, frame_index, guesses, geometry, part_val/idx/sec, nslots, ex
     const double *K64;           // l×l, column-major, dir·(g₊⊗g₊ − g₋⊗g₋) (:41-43); null = exact mode off
@@ -451,91 +451,104 @@ struct FinishGeo {
 
 constexpr int REFINE_NT = 256;
 
+constexpr int FINISH_WPB = REFINE_NT / 64; // windows per workgroup: a wave combines one window's partials
+
 static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const FinishGeo fg, const f2 *__restrict__ taps_row,
                                                                       const f2 *__restrict__ taps_col)
 {
     constexpr int NT = REFINE_NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_refine;
-    __shared__ float s_max;
+    __shared__ int s_refine[FINISH_WPB];
+    __shared__ float s_max[FINISH_WPB];
     const LaunchGeo &g = fg.g;
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x;
-    const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
-    if (tid < 64) { // wave 0: the slots' loads go out together (one memory round trip), then a shuffle merge
-        Peak pk;
-        peak_init(pk);
-        for (int s = tid; s < g.nslots; s += 64) peak_merge(pk, g.part_val[b * g.nslots + s], g.part_idx[b * g.nslots + s], g.part_sec[b * g.nslots + s]);
-        peak_wave_reduce(pk);
-        if (tid == 0) {
-            const bool rf = fg.K64 && (pk.best - pk.second <= g.ex.T);
-            range_check(g.ex, g1, g2, g.L >> 1, g.fh, g.fw);
-            if (rf) {
-                atomicAdd(g.ex.stat, 1ull);
-            } else {
-                const int x = pk.idx / g.n1, y = pk.idx - x * g.n1;
-                fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);       // :60-61
-                fg.out_ij[2 * b + 1] = min(max(g2 - g.r2 + x, 1), g.fw);
-                if (fg.done_flag && b == 0) __hip_atomic_store(fg.done_flag, fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // every wave: one window — the slots' loads go out together (one memory round trip), then a shuffle merge
+        const int b = blockIdx.x * FINISH_WPB + wave;
+        bool rf = false;
+        float best = 0.f;
+        if (b < g.n) {
+            Peak pk;
+            peak_init(pk);
+            for (int s = lane; s < g.nslots; s += 64) peak_merge(pk, g.part_val[b * g.nslots + s], g.part_idx[b * g.nslots + s], g.part_sec[b * g.nslots + s]);
+            peak_wave_reduce(pk);
+            if (lane == 0) {
+                const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
+                rf = fg.K64 && (pk.best - pk.second <= g.ex.T);
+                best = pk.best;
+                range_check(g.ex, g1, g2, g.L >> 1, g.fh, g.fw);
+                if (rf) {
+                    atomicAdd(g.ex.stat, 1ull);
+                } else {
+                    const int x = pk.idx / g.n1, y = pk.idx - x * g.n1;
+                    fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);       // :60-61
+                    fg.out_ij[2 * b + 1] = min(max(g2 - g.r2 + x, 1), g.fw);
+                    if (fg.done_flag && b == 0) __hip_atomic_store(fg.done_flag, fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
-            s_refine = rf;
-            s_max = pk.best;
         }
+        if (lane == 0) { s_refine[wave] = rf; s_max[wave] = best; }
     }
     __syncthreads();
-    if (!s_refine) return;
-    const int fidx = g.frame_index ? g.frame_index[b] : b;
-    const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
-    RefineCtx c;
-    c.trow = as_taps(taps_row);
-    c.tcol = as_taps(taps_col);
-    c.K = (k64_ptr)(unsigned long long)fg.K64;
-    c.g64 = (k64_ptr)(unsigned long long)fg.g64;
-    c.dir = fg.dir;
-    c.T64 = fg.T64;
-    c.T = g.ex.T;
-    c.cbw = fg.cbw;
-    c.tile_rows = fg.tile_rows;
-    c.lds = smem;
-    // the slots' maxima and column masks once, into LDS: `may` is asked once per column block
+    // the windows of this workgroup that need the refinement (rare), one after the other, all threads on each
     constexpr int SLOT_CAP = 128;
     __shared__ float s_pv[SLOT_CAP];
     __shared__ unsigned long long s_pm[SLOT_CAP];
-    const bool slots_ok = g.nslots <= SLOT_CAP;
-    if (slots_ok)
-        for (int s = tid; s < g.nslots; s += NT) {
-            s_pv[s] = g.part_val[(long long)b * g.nslots + s];
-            s_pm[s] = fg.use_mask ? g.part_mask[(long long)b * g.nslots + s] : ~0ull;
+    for (int w = 0; w < FINISH_WPB; ++w) {
+        if (!s_refine[w]) continue;
+        const int b = blockIdx.x * FINISH_WPB + w;
+        const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
+        const int fidx = g.frame_index ? g.frame_index[b] : b;
+        const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
+        RefineCtx c;
+        c.trow = as_taps(taps_row);
+        c.tcol = as_taps(taps_col);
+        c.K = (k64_ptr)(unsigned long long)fg.K64;
+        c.g64 = (k64_ptr)(unsigned long long)fg.g64;
+        c.dir = fg.dir;
+        c.T64 = fg.T64;
+        c.T = g.ex.T;
+        c.cbw = fg.cbw;
+        c.tile_rows = fg.tile_rows;
+        c.lds = smem;
+        // the slots' maxima and column masks once, into LDS: `may` is asked once per column block
+        const bool slots_ok = g.nslots <= SLOT_CAP;
+        __syncthreads();
+        if (slots_ok)
+            for (int s = tid; s < g.nslots; s += NT) {
+                s_pv[s] = g.part_val[(long long)b * g.nslots + s];
+                s_pm[s] = fg.use_mask ? g.part_mask[(long long)b * g.nslots + s] : ~0ull;
+            }
+        __syncthreads();
+        const float thr = s_max[w] - g.ex.T;
+        auto may = [&](int x0, int x1) {
+            if (!slots_ok) return true;
+            // main slots: slot s covers [min(s·slot_w, slot_last), + slot_w); only those that can intersect [x0, x1) are looked at
+            const int s_lo = max(0, x0 / fg.slot_w - 1), s_hi = min(fg.nmain, x1 / fg.slot_w + 2);
+            for (int s = s_lo; s < s_hi; ++s) {
+                const int lo = min(s * fg.slot_w, fg.slot_last), hi = lo + fg.slot_w;
+                if (lo < x1 && hi > x0 && s_pv[s] >= thr && ((s_pm[s] & column_bits(x0 - lo, x1 - lo)) || fg.slot_w != 64)) return true;
+            }
+            if (fg.slot_last < (1 << 29) && fg.nmain > 0) { // the roll kernel's last strip, shifted left: overlaps its predecessors
+                const int s = fg.nmain - 1, lo = fg.slot_last, hi = lo + fg.slot_w;
+                if (lo < x1 && hi > x0 && s_pv[s] >= thr && (s_pm[s] & column_bits(x0 - lo, x1 - lo))) return true;
+            }
+            for (int s = fg.nmain; s < g.nslots; ++s) { // thin columns
+                const int lo = fg.thin_x0 + (s - fg.nmain);
+                if (lo < x1 && lo >= x0 && s_pv[s] >= thr) return true;
+            }
+            return false;
+        };
+        const int idx = refine_window<16>(NT, g, frame, g1, g2, s_max[w], c, may);
+        if (tid == 0) {
+            const int x = idx / g.n1, y = idx - x * g.n1;
+            fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);
+            fg.out_ij[2 * b + 1] = min(max(g2 - g.r2 + x, 1), g.fw);
+            if (fg.done_flag && b == 0) {
+                __threadfence_system();
+                __hip_atomic_store(fg.done_flag, fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
-    __syncthreads();
-    const float thr = s_max - g.ex.T;
-    auto may = [&](int x0, int x1) {
-        if (!slots_ok) return true;
-        // main slots: slot s covers [min(s·slot_w, slot_last), + slot_w); only those that can intersect [x0, x1) are looked at
-        const int s_lo = max(0, x0 / fg.slot_w - 1), s_hi = min(fg.nmain, x1 / fg.slot_w + 2);
-        for (int s = s_lo; s < s_hi; ++s) {
-            const int lo = min(s * fg.slot_w, fg.slot_last), hi = lo + fg.slot_w;
-            if (lo < x1 && hi > x0 && s_pv[s] >= thr && (s >= fg.nmain || (s_pm[s] & column_bits(x0 - lo, x1 - lo)) || fg.slot_w != 64)) return true;
-        }
-        if (fg.slot_last < (1 << 29) && fg.nmain > 0) { // the roll kernel's last strip, shifted left: overlaps its predecessors
-            const int s = fg.nmain - 1, lo = fg.slot_last, hi = lo + fg.slot_w;
-            if (lo < x1 && hi > x0 && s_pv[s] >= thr && (s_pm[s] & column_bits(x0 - lo, x1 - lo))) return true;
-        }
-        for (int s = fg.nmain; s < g.nslots; ++s) { // thin columns
-            const int lo = fg.thin_x0 + (s - fg.nmain);
-            if (lo < x1 && lo >= x0 && s_pv[s] >= thr) return true;
-        }
-        return false;
-    };
-    const int idx = refine_window<16>(NT, g, frame, g1, g2, s_max, c, may);
-    if (tid == 0) {
-        const int x = idx / g.n1, y = idx - x * g.n1;
-        fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);
-        fg.out_ij[2 * b + 1] = min(max(g2 - g.r2 + x, 1), g.fw);
-        if (fg.done_flag && b == 0) {
-            __threadfence_system();
-            __hip_atomic_store(fg.done_flag, fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        __syncthreads();
     }
 }
 

@@ -505,7 +505,8 @@ int launch_finish(pdog_tracker *t, const LaunchGeo &g, int slot_w, int slot_last
     fg.done_flag = d_done_flag;
     fg.done_value = done_value;
     const size_t lds = t->exact ? refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_rows) : 0;
-    hipLaunchKernelGGL(dog_finish_kernel, dim3(g.n), dim3(REFINE_NT), lds, t->stream, fg, (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
+    hipLaunchKernelGGL(dog_finish_kernel, dim3((g.n + FINISH_WPB - 1) / FINISH_WPB), dim3(REFINE_NT), lds, t->stream, fg, (const f2 *)t->d_taps_row,
+                       (const f2 *)t->d_taps_col);
     HIP_TRY(hipGetLastError());
     return PDOG_OK;
 }
