@@ -18,7 +18,7 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 def _run(cmd, extra_env=None):
     env = dict(os.environ, **(extra_env or {}))
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
@@ -38,8 +38,12 @@ def test_bench_single_gpu_contract():
 
 
 def test_bench_two_rank_rehearsal():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-              "--master-port", "29517", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "128"],
+              "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "128"],
              {"PDOG_BENCH_BACKEND": "gloo"})
     for k in CONTRACT:
         assert k in r, k

@@ -71,7 +71,7 @@ def test_group_rejects_bad_devices(pt):
 _NCCL_WORLD1 = r"""
 import os, sys
 sys.path.insert(0, {root!r})
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="{port}", RANK="0", WORLD_SIZE="1")
 import torch, torch.distributed as dist
 import pawsometracker_jl_amd as pt
 dev = torch.device("cuda", 0)
@@ -91,7 +91,11 @@ print("nccl-world1-ok")
 def test_gather_positions_on_the_nccl_backend_world1():
     """torch.distributed's nccl backend IS RCCL on ROCm: device tensors, device_id= init, blocking and asynchronous
     gather — the calls bench.py makes with N > 1 — at world size 1, in a child process."""
-    p = subprocess.run([sys.executable, "-c", _NCCL_WORLD1.format(root=ROOT)], capture_output=True, text=True, timeout=600)
+    import socket
+    with socket.socket() as sk:          # a port nobody holds (a fixed one can sit in TIME_WAIT from an earlier run)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    p = subprocess.run([sys.executable, "-c", _NCCL_WORLD1.format(root=ROOT, port=port)], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "nccl-world1-ok" in p.stdout, (p.returncode, p.stderr[-1500:])
 
 
@@ -197,6 +201,8 @@ def test_switches_are_read_once_at_create(pt, oracle, monkeypatch):
     t1.close(); t2.close()
 
 
+@pytest.mark.skipif(not os.environ.get("PDOG_TEST_COOP"), reason="the cooperative chain is opt-in (slower than the default path) and waits on "
+                    "device-side barriers: run it on purpose with PDOG_TEST_COOP=1, not in the unattended suite")
 def test_cooperative_single_clip_chain(pt, oracle, monkeypatch):
     """A single clip whose window does not fit the fused kernel as ONE cooperative launch (csrc/dog_coop.hpp: resident
     workgroups, grid barriers between row pass, column pass and the finishing step; opt-in with PDOG_COOP=1 because it
