@@ -25,6 +25,7 @@
 // dozen dependent 4225-term chains per refined window.
 #pragma once
 #include "dog_kernels.hpp"
+#include <type_traits>
 
 namespace pdog {
 
@@ -164,9 +165,12 @@ struct RefineCtx {
 // loads: all NA rows at once when they fit (short kernels), otherwise slice by slice (a thread per row reading its own
 // row from memory was 10× slower: 64 cache lines per load instruction).  UNR: loads in flight per thread while staging.
 // Returns the window's answer (column-major index) in thread 0.
+// `map`: null, or the window's FP32 response as the main kernel wrote it (n1·n2 floats, column-major — the two-pass path
+// in exact mode): the candidates are then read off it instead of being recomputed (stage 1), and stage 2 only covers
+// the candidates' columns and the tile rows their sums reach.
 template <int UNR, typename May>
 __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, const uint8_t *__restrict__ frame, int g1, int g2, float M,
-                                             const RefineCtx &c, May may)
+                                             const RefineCtx &c, May may, const float *__restrict__ map = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = NT / 64;
     const int L = g.L, hw = L >> 1, NA = g.n1 + L - 1;
@@ -179,6 +183,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
     int *ired = cand_lin + REFINE_CAP;
     int *cnt = ired + 16; // [0] candidates found, [1] list overflowed, [2] survivors, [3] answer, [4] column blocks to rescan
     int *blk = cnt + 8;   // [REFINE_BLKCAP] first columns of the blocks to rescan
+    int *mm = blk + REFINE_BLKCAP; // [4] map path: candidates' column range, a column group's row range
     unsigned char *rbase = c.lds + refine_fixed_bytes();
     f2 *R32 = reinterpret_cast<f2 *>(rbase);
     double *R64 = reinterpret_cast<double *>(rbase);
@@ -210,33 +215,100 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
             const int k = atomicAdd(&cnt[4], 1);
             if (k < REFINE_BLKCAP) blk[k] = cb * c.cbw;
         }
+    if (tid == 0) { mm[0] = 0x7fffffff; mm[1] = -1; }
     __syncthreads();
     const bool blk_all = cnt[4] > REFINE_BLKCAP;
     const int nblk = blk_all ? nblk_all : cnt[4];
+    // with a response map: the candidates are read straight off it — every pixel of the listed blocks with f ≥ M − T —
+    // together with the column range they span
+    constexpr int MAP_KPT = 4; // candidates per thread in the map path's stage 2
+    bool use_map = map != nullptr && REFINE_CAP <= MAP_KPT * NT;
+    if (use_map) {
+        const int npx = g.n1 * g.n2, bw = c.cbw * g.n1, tot = nblk * bw;
+        for (int e0 = 0; e0 < tot; e0 += 8 * NT) {
+            float v[8];
+            int ee[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = e0 + u * NT + tid;
+                const int bi = i / bw, r = i - bi * bw;
+                const int e = (i < tot ? (blk_all ? bi * c.cbw : blk[bi]) : 0) * g.n1 + r;
+                const bool ok = i < tot && e < npx; // (the last block of a window may be narrower)
+                ee[u] = e;
+                v[u] = ok ? map[ok ? e : 0] : -__builtin_huge_valf();
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (v[u] >= thr) {
+                    const int k = atomicAdd(&cnt[0], 1);
+                    if (k < REFINE_CAP) cand_lin[k] = ee[u]; else cnt[1] = 1;
+                    const int x = ee[u] / g.n1;
+                    atomicMin(&mm[0], x);
+                    atomicMax(&mm[1], x);
+                }
+        }
+        __syncthreads();
+        if (cnt[1]) { // more candidates than the list holds (a plateau): the general path below deals with it
+            __syncthreads();
+            if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+            use_map = false;
+            __syncthreads();
+        }
+    }
     PDOG_STAMP(0);
 
     // rows [a0, a0 + rows) of the block's tile → LDS: a dword (4 pixels) per item, loaded unconditionally at an address
     // clamped into the frame (a clamped dword still holds every in-frame byte its item needs, at a shifted position),
     // the PaddedView fill (:48) selected afterwards — no branch between two loads, UNR of a thread's loads in flight
     auto stage = [&](int x0, int tp, int a0, int rows) {
-        const int tq = tp >> 2;
+        const int tq = tp >> 2, total = rows * tq;
+        const int gi0 = ti0 + a0, gj0 = wj0 + x0;
+        // Batches of UNR items per thread: first every load (a surplus item of the last batch loads item 0's address), then
+        // the stores — written as one loop with an exit test per item, each load waited for its own store (s_waitcnt vmcnt(0)
+        // after every global_load: 57 µs for a 90 KB tile).
         if (g.fw >= 4) {
-#pragma unroll UNR
-            for (int e = tid; e < rows * tq; e += NT) {
-                const int a = e / tq, q = e - a * tq;
-                const int gi = ti0 + a0 + a, gj = wj0 + x0 + 4 * q;
-                const int gjc = min(max(gj, 0), g.fw - 4);
-                uint32_t w;
-                __builtin_memcpy(&w, frame + (long long)min(max(gi, 0), g.fh - 1) * g.row_stride + gjc, 4);
-                const bool rowok = gi >= 0 && gi < g.fh;
-                uint32_t o = 0;
+            const bool inside = gi0 >= 0 && gi0 + rows <= g.fh && gj0 >= 0 && gj0 + tp <= g.fw; // the usual case: a plain dword copy
+            const uint8_t *base = frame + (long long)min(max(gi0, 0), g.fh - 1) * g.row_stride + min(max(gj0, 0), g.fw - 4);
+            int a = tid / tq, q = tid - a * tq; // (row, dword) of this thread's next item, stepped without a division
+            const int da = NT / tq, dq = NT - da * tq;
+            for (int e0 = tid; e0 < total; e0 += UNR * NT) {
+                uint32_t w[UNR];
+                int ra[UNR], rq[UNR];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int gjj = gj + i;
-                    const uint32_t px = (rowok && gjj >= 0 && gjj < g.fw) ? ((w >> (8 * ((gjj - gjc) & 3))) & 0xffu) : (uint32_t)g.fill;
-                    o |= px << (8 * i);
+                for (int u = 0; u < UNR; ++u) {
+                    const bool ok = e0 + u * NT < total;
+                    ra[u] = a;
+                    rq[u] = q;
+                    const uint8_t *src = base;
+                    if (inside) {
+                        if (ok) src = base + (long long)a * g.row_stride + 4 * q;
+                    } else if (ok) { // clamped into the frame: a clamped dword still holds every in-frame byte its item needs, at a shifted position
+                        const int gi = gi0 + a, gj = gj0 + 4 * q;
+                        src = frame + (long long)min(max(gi, 0), g.fh - 1) * g.row_stride + min(max(gj, 0), g.fw - 4);
+                    }
+                    __builtin_memcpy(&w[u], src, 4);
+                    a += da;
+                    q += dq;
+                    if (q >= tq) { q -= tq; ++a; }
                 }
-                *reinterpret_cast<uint32_t *>(tile + a * tp + 4 * q) = o;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    if (e0 + u * NT >= total) continue;
+                    uint32_t o = w[u];
+                    if (!inside) { // the PaddedView fill (:48) for the bytes outside the frame
+                        const int gi = gi0 + ra[u], gj = gj0 + 4 * rq[u];
+                        const int gjc = min(max(gj, 0), g.fw - 4);
+                        const bool rowok = gi >= 0 && gi < g.fh;
+                        o = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int gjj = gj + i;
+                            const uint32_t px = (rowok && gjj >= 0 && gjj < g.fw) ? ((w[u] >> (8 * ((gjj - gjc) & 3))) & 0xffu) : (uint32_t)g.fill;
+                            o |= px << (8 * i);
+                        }
+                    }
+                    *reinterpret_cast<uint32_t *>(tile + ra[u] * tp + 4 * rq[u]) = o;
+                }
             }
         } else {
             for (int e = tid; e < rows * tp; e += NT) {
@@ -378,7 +450,146 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
         return pk;
     };
 
-    Peak64 pk = sweep(false);
+    // map path, stage 2.  The candidates' columns in groups of ≤ 16; per group the tile rows its candidates' sums reach,
+    // slice by slice: pixels → LDS once, Float64 row sums of both Gaussians for the group's columns (symmetric taps: the
+    // two pixels of a tap pair are added as integers — exact — so a pair costs one conversion and two FMAs), and every
+    // candidate of the group (≤ MAP_KPT per thread, sums in registers) takes up the slice's share of its column sums.
+    // Raw pixel units; the N0f8 scale 1/255 is applied once at the end.  Error (4l + 8)·2⁻⁵³, inside δ64's allowance.
+    auto from_map = [&]() {
+        const int n = cnt[0], H = L >> 1;
+        const int xmin = mm[0], xmax = mm[1];
+        const size_t rbytes = refine_r_bytes(g.n1, L, c.cbw), tbytes = refine_tile_bytes(c.tile_rows, L, c.cbw);
+        // TPC lanes share a candidate's taps (a few dozen candidates would otherwise keep a few dozen lanes busy)
+        int TPC = 64;
+        while (TPC > 1 && n * TPC > MAP_KPT * NT) TPC >>= 1;
+        const int cpp = NT / TPC, sub = tid & (TPC - 1);
+        double sp[MAP_KPT], sm[MAP_KPT];
+        int cx[MAP_KPT], cy[MAP_KPT];
+#pragma unroll
+        for (int j = 0; j < MAP_KPT; ++j) {
+            const int k = tid / TPC + j * cpp;
+            cx[j] = -1; cy[j] = 0; sp[j] = 0.0; sm[j] = 0.0;
+            if (k < n) { const int lin = cand_lin[k]; cx[j] = lin / g.n1; cy[j] = lin - cx[j] * g.n1; }
+        }
+        int CW = 16;
+        while (CW > 4 && ((size_t)refine_tile_pitch(CW, L) > tbytes || (size_t)CW * 16 > rbytes)) CW -= 4;
+        for (int xg = xmin; xg <= xmax; xg += CW) {
+            const int ncol = min(CW, xmax + 1 - xg);
+            __syncthreads();
+            if (tid == 0) { mm[2] = 0x7fffffff; mm[3] = -1; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < MAP_KPT; ++j)
+                if (cx[j] >= xg && cx[j] < xg + ncol) { atomicMin(&mm[2], cy[j]); atomicMax(&mm[3], cy[j]); }
+            __syncthreads();
+            const int ymin = mm[2], ymax = mm[3];
+            if (ymax < 0) continue; // no candidate in this group of columns
+            if (tid == 0) atomicAdd(g.ex.stat + 1, 1ull);
+            const int rows_tot = ymax - ymin + L, tp = refine_tile_pitch((ncol + 3) & ~3, L); // (whole groups of four columns)
+            int RSm = max(1, (int)min((size_t)rows_tot, min(tbytes / tp, rbytes / ((size_t)ncol * 16))));
+            {   // whole rounds of NT (row, group of four columns) items
+                const int ng = (ncol + 3) >> 2;
+                if ((RSm * ng) / NT >= 1 && RSm < rows_tot) RSm = ((RSm * ng) / NT * NT) / ng;
+            }
+            for (int a0 = 0; a0 < rows_tot; a0 += RSm) {
+                const int rows = min(RSm, rows_tot - a0);
+                stage(xg, tp, ymin + a0, rows);
+                PDOG_STAMP(1);
+                // Row sums: a thread takes one tile row and FOUR adjacent columns.  Symmetric taps: column c's pair k is
+                // F[c + k] + F[c + l−1−k] (F: the row's bytes from the group's first column), so a block of four taps needs
+                // seven consecutive bytes at the front and seven at the back — one new aligned dword per side and block,
+                // each byte converted to double once and shared by the columns (read byte by byte per column, the LDS
+                // pipe was the limit: 2 reads per 2 FMAs).  Eight FMA chains per thread; the two physical windows of a
+                // side swap roles every block, so nothing is moved.
+                const int ngrp = (ncol + 3) >> 2, nitem = rows * ngrp, M4 = (L - 1) >> 2; // l = 4·M4 + 1
+                auto cvt4 = [](uint32_t w, double (&d)[4]) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d[i] = (double)((w >> (8 * i)) & 0xffu);
+                };
+                for (int e = tid; e < nitem; e += NT) {
+                    const int a = e / ngrp, cg = e - a * ngrp;
+                    const uint8_t *fb = tile + a * tp + 4 * cg;
+                    const uint32_t *fw4 = reinterpret_cast<const uint32_t *>(fb);
+                    double rp[4], rm[4];
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) { rp[cc] = 0.0; rm[cc] = 0.0; }
+                    double fa[4], fbk[4], ha[4], hb[4]; // front: dwords q, q+1; back: dwords M4−q−1 (ha), M4−q (hb), q = k0/4
+                    cvt4(fw4[0], fa);
+                    cvt4(fw4[1], fbk);
+                    cvt4(fw4[M4 - 1], ha);
+                    cvt4(fw4[M4], hb);
+                    // one block of four taps k0 … k0+3: lo = (LO0, LO1) = bytes k0 … k0+7, back window (HA, HB) = bytes l−1−k0−4 … l−1−k0+3
+                    auto block = [&](const double (&LO0)[4], const double (&LO1)[4], const double (&HA)[4], const double (&HB)[4], const double *gp, const double *gm) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc) {
+                                const int li = cc + u, hi = 4 + cc - u; // front byte k0 + li; back byte (l−1−k0−4) + hi
+                                const double v = (li < 4 ? LO0[li] : LO1[li - 4]) + (hi < 4 ? HA[hi] : HB[hi - 4]);
+                                rp[cc] = __builtin_fma(gp[u], v, rp[cc]);
+                                rm[cc] = __builtin_fma(gm[u], v, rm[cc]);
+                            }
+                    };
+                    int k0 = 0;
+                    for (; k0 + 8 <= H; k0 += 8) {
+                        double gp[8], gm[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { gp[u] = c.g64[k0 + u]; gm[u] = c.g64[L + k0 + u]; }
+                        const int q = k0 >> 2;
+                        const uint32_t nf0 = fw4[q + 2], nh0 = fw4[M4 - q - 2], nf1 = fw4[q + 3], nh1 = fw4[max(M4 - q - 3, 0)];
+                        block(fa, fbk, ha, hb, gp, gm);
+                        cvt4(nf0, fa);  // fa ← dword q+2, hb ← dword M4−q−2: the next block's (lo1, ha)
+                        cvt4(nh0, hb);
+                        block(fbk, fa, hb, ha, gp + 4, gm + 4);
+                        cvt4(nf1, fbk); // back to the first block's roles, two dwords on
+                        cvt4(nh1, ha);
+                    }
+                    // the remaining pairs (fewer than 8) one at a time, then the centre tap (k = H) on its own
+                    for (int k = k0; k <= H; ++k) {
+                        const double gpk = c.g64[k], gmk = c.g64[L + k];
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) {
+                            const double v = (double)(k < H ? (int)fb[cc + k] + (int)fb[cc + L - 1 - k] : (int)fb[cc + H]);
+                            rp[cc] = __builtin_fma(gpk, v, rp[cc]);
+                            rm[cc] = __builtin_fma(gmk, v, rm[cc]);
+                        }
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
+                        if (4 * cg + cc < ncol) { R64[2 * (a * ncol + 4 * cg + cc)] = rp[cc]; R64[2 * (a * ncol + 4 * cg + cc) + 1] = rm[cc]; }
+                }
+                __syncthreads();
+                PDOG_STAMP(4);
+#pragma unroll
+                for (int j = 0; j < MAP_KPT; ++j) {
+                    if (cx[j] < xg || cx[j] >= xg + ncol) continue;
+                    const int x = cx[j] - xg, y = cy[j] - ymin;
+                    const int t0 = max(0, a0 - y), t1 = min(L, a0 + rows - y); // taps whose rows lie in this slice
+                    const double *r = R64 + 2 * ((y - a0) * ncol + x);
+                    double p = sp[j], m = sm[j];
+#pragma unroll 4
+                    for (int t = t0 + sub; t < t1; t += TPC) {
+                        p = __builtin_fma(c.g64[t], r[2 * t * ncol], p);
+                        m = __builtin_fma(c.g64[L + t], r[2 * t * ncol + 1], m);
+                    }
+                    sp[j] = p; sm[j] = m;
+                }
+                PDOG_STAMP(5);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MAP_KPT; ++j) {
+            double p = sp[j], m = sm[j];
+            for (int off = TPC >> 1; off > 0; off >>= 1) { p += __shfl_xor(p, off, 64); m += __shfl_xor(m, off, 64); }
+            if (cx[j] >= 0 && sub == 0) cand_val[tid / TPC + j * cpp] = c.dir * (p - m) / 255.0;
+        }
+        __syncthreads();
+    };
+
+    Peak64 pk;
+    pk.best = -__builtin_huge_val();
+    pk.idx = 0x7fffffff;
+    if (use_map) from_map(); else pk = sweep(false);
     const bool overflow = cnt[1] != 0;
     if (overflow) {
         __syncthreads();
@@ -444,6 +655,7 @@ struct FinishGeo {
     // are single columns thin_x0 + (s − nmain)
     int slot_w, slot_last, nmain, thin_x0;
     int use_mask;                // the main slots carry per-column masks (roll kernel, slot_w = 64)
+    const float *map;            // null, or the batch's FP32 responses [n][n2][n1] (two-pass path): refine_window reads the candidates off it
     int32_t *out_ij;             // [n][2]
     int32_t *done_flag;          // NULL or host-coherent ticket word (see dog_fused.hpp): published with window 0's final answer
     int32_t done_value;
@@ -538,7 +750,7 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
             }
             return false;
         };
-        const int idx = refine_window<16>(NT, g, frame, g1, g2, s_max[w], c, may);
+        const int idx = refine_window<16>(NT, g, frame, g1, g2, s_max[w], c, may, fg.map ? fg.map + (long long)b * g.n1 * g.n2 : nullptr);
         if (tid == 0) {
             const int x = idx / g.n1, y = idx - x * g.n1;
             fg.out_ij[2 * b] = min(max(g1 - g.r1 + y, 1), g.fh);

@@ -63,6 +63,7 @@ struct Switches {
     bool coop = false;                    // PDOG_COOP: single-clip chains of large windows as ONE cooperative launch (dog_coop.hpp; measured slower
                                           // than the three stream-ordered launches per frame it replaces, so off by default)
     size_t scratch_cap = (size_t)6 << 30; // HBM scratch of the two-pass intermediate; larger batches go in chunks
+    size_t map_cap = (size_t)4 << 30;     // PDOG_MAP_MB: largest FP32 response map the two-pass path keeps for exact mode (beyond: candidates are recomputed)
     int fused_pr = 0, fused_pc = 0;       // PDOG_FUSED_P=pr,pc (0: chosen per geometry)
     int host_threads = 0;                 // PDOG_HOST_THREADS (0: min(16, cores))
     int ingest_chunk = 0;                 // PDOG_INGEST_CHUNK (0: ≈32 MB of tiles)
@@ -83,6 +84,7 @@ Switches read_switches()
     w.no_exact = on("PDOG_NO_EXACT");
     w.coop = on("PDOG_COOP");
     if (const char *e = std::getenv("PDOG_SCRATCH_MB")) w.scratch_cap = (size_t)std::max(1, std::atoi(e)) << 20;
+    if (const char *e = std::getenv("PDOG_MAP_MB")) w.map_cap = (size_t)std::max(0, std::atoi(e)) << 20;
     if (const char *e = std::getenv("PDOG_FUSED_P")) {
         int a = 0, b = 0;
         if (std::sscanf(e, "%d,%d", &a, &b) == 2 && (a == 3 || a == 4 || a == 5 || a == 6 || a == 8) &&
@@ -239,6 +241,8 @@ struct pdog_tracker {
     // two-pass path scratch
     f2 *d_V = nullptr;
     size_t v_bytes = 0;
+    float *d_map = nullptr; // exact mode on the two-pass path: the batch's FP32 responses, where the refinement finds its candidates
+    size_t map_bytes = 0;
     int *d_dc = nullptr;
     int dc_cap = 0;
     int *d_counter = nullptr;  // [kLowLatMax] zero between launches: delivered column-pass partials per window (low-latency two-pass)
@@ -486,10 +490,11 @@ ExactCtl exact_ctl(const pdog_tracker *t)
 // can hold a near-maximal pixel).  With done_flag set the kernel also publishes the host functor's ticket with
 // window 0's final answer.
 int launch_finish(pdog_tracker *t, const LaunchGeo &g, int slot_w, int slot_last, int32_t *d_out_ij, int32_t *d_done_flag, int32_t done_value,
-                  bool use_mask = false)
+                  bool use_mask = false, const float *map = nullptr)
 {
     FinishGeo fg;
     fg.g = g;
+    fg.map = map;
     fg.K64 = t->exact ? t->d_K64 : nullptr;
     fg.g64 = t->d_g64;
     fg.dir = t->darker ? -1.0 : 1.0;
@@ -613,6 +618,24 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         g.nstrips = tp_slots;
         g.nslots = tp_slots;
         g.nthin = 0;
+        // exact mode: the column pass also writes its responses (4 B per pixel), so that a window that needs the
+        // refinement — every window, at the σ this path serves — reads its candidates off the map instead of recomputing them
+        const float *map = d_out_resp;
+        if (t->exact && !map) {
+            const size_t need = sizeof(float) * (size_t)n * t->n1 * t->n2;
+            if (need <= t->sw.map_cap) {
+                if (t->map_bytes < need) {
+                    HIP_TRY(hipStreamSynchronize(t->stream));
+                    if (t->d_map) (void)hipFree(t->d_map);
+                    t->d_map = nullptr; t->map_bytes = 0;
+                    HIP_TRY(hipMalloc(&t->d_map, need));
+                    t->map_bytes = need;
+                }
+                map = t->d_map;
+                g.resp = t->d_map;
+            }
+        }
+        const bool want_resp = g.resp != nullptr;
         TwoPassGeo tg;
         tg.g = g;
         tg.TWin = t->n2 + t->L - 1;
@@ -659,12 +682,12 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
             if (ticket_armed) *ticket_armed = d_done_flag != nullptr;
             hipLaunchKernelGGL((dog_h1_kernel<13, 8, true>), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
             HIP_TRY(hipGetLastError());
-            if (d_out_resp)
+            if (want_resp)
                 hipLaunchKernelGGL((dog_hpass_kernel<7, 16, true, 8>), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             else
                 hipLaunchKernelGGL((dog_hpass_kernel<7, 16, false, 8>), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             HIP_TRY(hipGetLastError());
-            return launch_finish(t, g, hr, 1 << 30, d_out_ij, d_done_flag, done_value);
+            return launch_finish(t, g, hr, 1 << 30, d_out_ij, d_done_flag, done_value, false, t->exact ? map : nullptr);
         }
         if (lowlat) {
             if (!t->d_counter) {
@@ -678,7 +701,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
             if (ticket_armed) *ticket_armed = d_done_flag != nullptr;
             hipLaunchKernelGGL((dog_h1_kernel<13, 8, true>), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
             HIP_TRY(hipGetLastError());
-            if (d_out_resp)
+            if (want_resp)
                 hipLaunchKernelGGL((dog_hpass_kernel<7, 16, true, 8, true>), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             else
                 hipLaunchKernelGGL((dog_hpass_kernel<7, 16, false, 8, true>), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
@@ -693,17 +716,17 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
             hipLaunchKernelGGL((dog_h1_kernel<13, 8>), dim3(nw * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
             HIP_TRY(hipGetLastError());
             if (hr == 8) {
-                if (d_out_resp)
+                if (want_resp)
                     hipLaunchKernelGGL((dog_hpass_kernel<7, 16, true, 8>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
                 else
                     hipLaunchKernelGGL((dog_hpass_kernel<7, 16, false, 8>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
-            } else if (d_out_resp)
+            } else if (want_resp)
                 hipLaunchKernelGGL((dog_hpass_kernel<13, 16, true>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             else
                 hipLaunchKernelGGL((dog_hpass_kernel<13, 16, false>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             HIP_TRY(hipGetLastError());
         }
-        return launch_finish(t, g, hr, 1 << 30, d_out_ij, nullptr, 0);
+        return launch_finish(t, g, hr, 1 << 30, d_out_ij, nullptr, 0, false, t->exact ? map : nullptr);
     }
     const int grid = round_up(g.nblocks, 8);
     if (t->nthin) {
@@ -966,6 +989,7 @@ int pdog_destroy(pdog_tracker *t)
     if (t->d_resp) (void)hipFree(t->d_resp);
     if (t->h_tile) (void)hipHostFree(t->h_tile);
     if (t->d_V) (void)hipFree(t->d_V);
+    if (t->d_map) (void)hipFree(t->d_map);
     if (t->d_dc) (void)hipFree(t->d_dc);
     if (t->d_counter) (void)hipFree(t->d_counter);
     if (t->d_chain_tmp) (void)hipFree(t->d_chain_tmp);

@@ -227,3 +227,39 @@ def test_full_size_census(pt, oracle, cfg):
     print(f"{cfg}: {n} windows, refined {refined}, GPU vs separable-f64 disagreements {len(disagree)} (all adjudicated for the GPU by the "
           f"dense oracle), FP32 ranking alone differs from exact mode on {wrong_raw}")
     assert on and len(disagree) <= n // 100
+
+
+def test_response_map_path_equals_rescan_path(pt, monkeypatch):
+    """Two-pass path in exact mode: the candidates of a flagged window are read off the FP32 response map the column pass
+    wrote (csrc/dog_exact.hpp, `map`); with PDOG_MAP_MB=0 (read once, at create) they are recomputed block by block as
+    on the other paths.  Same candidates, same positions — on hard 45×45 windows (l = 65, two-pass forced) and on
+    wide-target windows (tw = 120, l = 293: every window flagged)."""
+    import torch
+    def run(frames, guesses, tw, ws, variant):
+        bt = pt.BatchTracker(frames.shape[1], frames.shape[2], tw, ws, True, 128)
+        if variant >= 0:
+            bt.set_variant(variant)
+        out = bt.detect(torch.from_numpy(frames).cuda(), torch.from_numpy(guesses).cuda())
+        bt.sync()
+        res = out.cpu().numpy(), bt.exact_stats()[2], bt.exact_detail()
+        bt.close()
+        return res
+
+    frames, guesses, _ = _hard_windows(4096, 128, 128, 25, seed=5)
+    rng = np.random.Generator(np.random.PCG64(8))
+    wide = (128 + rng.integers(-3, 4, (48, 480, 640))).astype(np.uint8)
+    yy, xx = np.mgrid[0:480, 0:640]
+    wg = np.empty((48, 2), np.int32)
+    for b in range(48):
+        ci, cj = int(rng.integers(150, 330)), int(rng.integers(200, 440))
+        wide[b][(yy - ci) ** 2 + (xx - cj) ** 2 <= 60 * 60] = 10
+        wg[b] = (ci + int(rng.integers(-20, 21)), cj + int(rng.integers(-20, 21)))
+    cases = [(frames, guesses, 25, (45, 45), 200), (wide, wg, 120, None, -1)]
+    with_map = [run(f, g, tw, ws if ws else (205, 205), v) for f, g, tw, ws, v in cases]
+    monkeypatch.setenv("PDOG_MAP_MB", "0")
+    without = [run(f, g, tw, ws if ws else (205, 205), v) for f, g, tw, ws, v in cases]
+    for (pa, ra, da), (pb, rb, db) in zip(with_map, without):
+        assert np.array_equal(pa, pb)
+        assert ra == rb and ra > 0
+        assert abs(da[2] - db[2]) <= 1e-3 * db[2]   # the same candidates (up to the rescan's own FP32 rounding at the threshold) …
+        assert da[1] <= db[1]               # … from fewer column blocks
