@@ -136,35 +136,41 @@ __device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restr
         f2 acc[P];
 #pragma unroll
         for (int o = 0; o < P; ++o) acc[o] = f2{0.f, 0.f};
-        float lo[P + U - 1], hi[P + U - 1];
+        // The two sliding windows live in register RINGS of R slots (slot = input index mod R on the front side, counted
+        // from the block's own origin on the back side): with NB = R/U blocks per trip every slot index is a constant, so
+        // sliding costs nothing (shifting the windows by U per block took 52 v_mov_b32 beside 104 + 104 arithmetic
+        // instructions: 14 % of the loop's issue time).
+        constexpr int R = ((P + 2 * U - 1 + U - 1) / U) * U, NB = R / U;
+        float lo[R], hi[R];
 #pragma unroll
         for (int j = 0; j < P + U - 1; ++j) {
             lo[j] = ld(j);
             hi[j] = ld(L - U + j);
         }
-        int k0 = 0;
-        for (; k0 + U <= H; k0 += U) {
-            float nlo[U], nhi[U];
+        auto block = [&](int sb, int k0) { // sb = (k0 / U) mod NB: a constant after unrolling
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                nlo[j] = ld(k0 + U + (P - 1) + j);
-                nhi[j] = ld(L - U - (k0 + U) + j);
+            for (int j = 0; j < U; ++j) { // the next block's new ends, requested before this block's arithmetic
+                lo[(sb * U + P + U - 1 + j) % R] = ld(k0 + U + (P - 1) + j);
+                hi[(j + 2 * R - (sb + 1) * U) % R] = ld(L - U - (k0 + U) + j);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const f2 t = taps[k0 + u];
 #pragma unroll
-                for (int o = 0; o < P; ++o) acc[o] = fma_bcast(lo[o + u] + hi[o + (U - 1) - u], t, acc[o]);
+                for (int o = 0; o < P; ++o)
+                    acc[o] = fma_bcast(lo[(sb * U + o + u) % R] + hi[(o + (U - 1) - u + R - sb * U) % R], t, acc[o]);
             }
+        };
+        const int nb = H / U;
+        int bk = 0;
+        for (; bk + NB <= nb; bk += NB) {
 #pragma unroll
-            for (int j = 0; j < P - 1; ++j) lo[j] = lo[j + U];
-#pragma unroll
-            for (int j = 0; j < U; ++j) lo[P - 1 + j] = nlo[j];
-#pragma unroll
-            for (int j = P + U - 2; j >= U; --j) hi[j] = hi[j - U];
-#pragma unroll
-            for (int j = 0; j < U; ++j) hi[j] = nhi[j];
+            for (int sb = 0; sb < NB; ++sb) block(sb, (bk + sb) * U);
         }
+#pragma unroll
+        for (int sb = 0; sb < NB - 1; ++sb)
+            if (bk + sb < nb) block(sb, (bk + sb) * U);
+        int k0 = nb * U;
         // remaining symmetric pairs (H − k0 < U) one tap at a time, then the centre tap
         for (; k0 < H; ++k0) {
             const f2 t = taps[k0];
@@ -241,32 +247,33 @@ __device__ __forceinline__ Peak hpass_block(const TwoPassGeo &tg, const f2 *__re
         for (int o = 0; o < P; ++o) acc[o] = f2{0.f, 0.f};
         // rows are staged out to the LDS pitch (zeros past NA): no clamp on the window reads
         auto ld = [&](int i) { return a[i]; };
-        f2 win[P + U - 1];
+        // The sliding window is a register RING of R slots (slot = input index mod R; NB = R/U blocks per trip make every
+        // slot index a constant — shifting the window took 22 v_mov_b64 + 15 v_mov_b32 per 112 FMAs), and the taps are
+        // taken in whole blocks of U: the tap table ends in ≥ U zeros and the LDS rows in zeros, so the l mod U surplus
+        // terms add 0·(finite) = 0 exactly (the one-tap-at-a-time tail they replace shifted the whole window per tap).
+        constexpr int R = ((P + 2 * U - 1 + U - 1) / U) * U, NB = R / U;
+        f2 win[R];
 #pragma unroll
         for (int j = 0; j < P + U - 1; ++j) win[j] = ld(j);
-        int k0 = 0;
-        for (; k0 + U <= L; k0 += U) {
-            f2 nw[U];
+        auto block = [&](int sb, int k0) { // sb = (k0 / U) mod NB: a constant after unrolling
 #pragma unroll
-            for (int j = 0; j < U; ++j) nw[j] = ld(k0 + U + (P - 1) + j);
+            for (int j = 0; j < U; ++j) win[(sb * U + P + U - 1 + j) % R] = ld(k0 + U + (P - 1) + j);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const f2 t = taps[k0 + u];
 #pragma unroll
-                for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[o + u], t, acc[o]);
+                for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[(sb * U + o + u) % R], t, acc[o]);
             }
+        };
+        const int nb = (L + U - 1) / U;
+        int bk = 0;
+        for (; bk + NB <= nb; bk += NB) {
 #pragma unroll
-            for (int j = 0; j < P - 1; ++j) win[j] = win[j + U];
-#pragma unroll
-            for (int j = 0; j < U; ++j) win[P - 1 + j] = nw[j];
+            for (int sb = 0; sb < NB; ++sb) block(sb, (bk + sb) * U);
         }
-        for (; k0 < L; ++k0) { // l mod U leftover taps, one at a time (window = win[0..P-1] shifted by one)
-            const f2 t = taps[k0];
 #pragma unroll
-            for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[o], t, acc[o]);
-#pragma unroll
-            for (int j = 0; j < P + U - 2; ++j) win[j] = win[j + 1];
-        }
+        for (int sb = 0; sb < NB - 1; ++sb)
+            if (bk + sb < nb) block(sb, (bk + sb) * U);
         if (r < nrows) {
             const int x = r0 + r;
 #pragma unroll

@@ -297,7 +297,7 @@ fused_fn_t fused_kernel_for(int L, bool resp);
 
 // LDS row pitches of the two-pass kernels: the sliding windows (and their one-block prefetch) of the last,
 // partly masked group of 13 outputs must stay inside the zero-padded row.  nout outputs, l taps.
-int twopass_pitch(int nout, int L, int rows = HP_ROWS) { return (round_up(nout, rows == 8 ? 32 * 7 : 16 * 13) + L + 16) | 1; }
+int twopass_pitch(int nout, int L, int rows = HP_ROWS) { return (round_up(nout, rows == 8 ? 32 * 7 : 16 * 13) + L + 48) | 1; } // (l rounded up to a block of 16 taps + one block of prefetch)
 
 // Exact mode's refinement (dog_exact.hpp) works on blocks of `cbw` window columns whose row-pass result (two doubles
 // per element in the Float64 stage) fits ≈24 KB of LDS; the block's pixels go through an LDS tile — all n1 + l − 1 rows
