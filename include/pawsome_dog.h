@@ -107,8 +107,9 @@ int pdog_get_stream(const pdog_tracker *t, void **out_hip_stream);
 /* Pre-size the per-window workspace so pdog_detect_batch never allocates. */
 int pdog_reserve(pdog_tracker *t, int max_windows);
 /* The kernel family a batch of n windows would run on (variant id: 300 = one workgroup per window,
- * 200 = two-pass, otherwise the tracker's batch kernel as in pdog_info.variant): small batches are
- * switched at launch to whatever can fill the GPU.  For reporting. */
+ * 400 = one workgroup per sub-window of a large window (one or two windows, single-clip chains), 200 = two-pass,
+ * otherwise the tracker's batch kernel as in pdog_info.variant): small batches are switched at launch to whatever
+ * can fill the GPU.  For reporting. */
 int pdog_kernel_for_batch(const pdog_tracker *t, int n, int *out_variant);
 /* Force a kernel specialisation (tuning/tests); -1 = automatic. */
 int pdog_set_variant(pdog_tracker *t, int variant);

@@ -46,7 +46,7 @@ class BatchTracker:
         return tuple(int(v) for v in out)
 
     def kernel_for_batch(self, n):
-        """Variant id of the kernel family a batch of n windows runs on (300 fused, 200 two-pass, else info().variant)."""
+        """Variant id of the kernel family a batch of n windows runs on (300 fused, 400 tiled, 200 two-pass, else info().variant)."""
         o = C.c_int()
         _lib.check(_lib.lib().pdog_kernel_for_batch(self._h, int(n), C.byref(o)))
         return o.value

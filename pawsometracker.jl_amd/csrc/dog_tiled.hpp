@@ -1,0 +1,316 @@
+// dog_tiled.hpp — DoG + argmax for ONE large search window per frame (e.g. 257×257 around a 25-px target), the latency
+// path of a single clip: the window is cut into sub-windows that each fit one CU's LDS, one 1024-thread workgroup per
+// sub-window runs the whole pipeline of the fused kernel (dog_fused.hpp) on its piece, and the workgroup that delivers
+// the last partial peak combines them (reference functor /root/reference/src/PawsomeTracker.jl:55-62, frame loop :163-169).
+//
+// Why: the two-pass kernels spread such a window over ≈50 workgroups but need the row-pass result to cross HBM and
+// three stream-ordered launches per frame (row pass, column pass, finish: ≈27 µs per 257×257 frame, ≈50 µs per host
+// functor call); one cooperative launch with grid barriers between the passes was slower still (dog_coop.hpp: a
+// frame is ≈12 dependent memory round trips).  Here a frame is: samples + tile (one round trip) → both passes in LDS →
+// one partial per sub-window → the last arrival combines → the next guess (one more round trip).  The price is the
+// halo: each sub-window runs its row pass over l − 1 extra tile rows (2× the row-pass work at 43×43 sub-windows,
+// l = 65) — irrelevant where latency, not throughput, is what a single clip sees.
+//
+// Arithmetic per output: exactly the fused kernel's (same tasks, same tap order), with the DC level taken from the
+// FULL window's sample grid, so every sub-window subtracts the same level and flat regions tie exactly across
+// sub-window borders; indices are the full window's column-major indices, ties → the smallest (findmax, :59).
+// Chains (chain_len > 1) keep all workgroups of a clip resident and spinning on the clip's frame flag: the host
+// launches them cooperatively (co-residency guaranteed or refused).
+#pragma once
+#include "dog_fused.hpp"
+
+namespace pdog {
+
+struct TiledGeo {
+    LaunchGeo g;            // full-window geometry; part_val / part_idx / part_sec: [n_clips][2][nsub] (two sets, by frame parity)
+    int NA, TWin;           // the FULL window's padded tile (for the DC sample grid)
+    int sn1, sn2;           // sub-window rows / columns (the last ones are smaller)
+    int ns1, ns2;           // sub-windows per window column / row; nsub = ns1·ns2, sub-window s = s2·ns1 + s1
+    int pitchA, pitchV;     // LDS pitches for the largest sub-window (fused_pitch_a/v)
+    int cshift, pr, pc;     // staging threads per tile row (2^cshift), outputs per task (see dog_fused.hpp)
+    int chain_len;          // frames per clip; clip c = frames c·chain_len …
+    int32_t *out_ij;        // [n_clips][chain_len][2]
+    int32_t *done_flag;     // NULL, or host-coherent word: done_value after clip 0's last frame, or k + 1 after each frame (progress)
+    int32_t done_value;
+    int progress;
+    const RefineParams *rp; // exact mode (null = off)
+    int ref_cbw, ref_rows;  // refinement scratch geometry inside this kernel's LDS
+    int *cur;               // [n_clips][2]: the current guess, last arrival → everyone
+    unsigned *sync;         // [n_clips][2], zero when a launch starts and when it ends: partial arrivals, frame flag (set after a refined frame only)
+};
+
+constexpr int TILED_SLOT_CAP = 256; // sub-windows per window the combining wave handles (4 per lane)
+
+template <bool RESP>
+__global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, const f2 *__restrict__ taps_row,
+                                                             const f2 *__restrict__ taps_col)
+{
+    const LaunchGeo &g = tg.g;
+    constexpr int NT = FUSED_NT, NW = NT / 64, U = FUSED_U;
+    const int L = g.L, hw = L >> 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *A = reinterpret_cast<float *>(smem);
+    f2 *Vs = reinterpret_cast<f2 *>(smem + fused_a_bytes(tg.sn1, tg.sn2, L));
+    __shared__ int s_sum[NW];
+    __shared__ float s_val[NW], s_sec[NW];
+    __shared__ int s_idx[NW];
+    __shared__ int s_last, s_refine;
+    __shared__ float s_max;
+    __shared__ float s_pv[TILED_SLOT_CAP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nsub = tg.ns1 * tg.ns2;
+    const int clip = blockIdx.x / nsub, s = blockIdx.x - clip * nsub;
+    const int s2 = s / tg.ns1, s1 = s - s2 * tg.ns1;
+    const int sy = s1 * tg.sn1, sx = s2 * tg.sn2;                   // this sub-window's first row / column in the window
+    const int m1 = min(tg.sn1, g.n1 - sy), m2 = min(tg.sn2, g.n2 - sx); // its size
+    const int NAs = m1 + L - 1, TWs = m2 + L - 1;                   // its padded tile
+    const tap_ptr trow = as_taps(taps_row), tcol = as_taps(taps_col);
+    float *const pv = g.part_val + (long long)clip * 2 * nsub;
+    int *const pi = g.part_idx + (long long)clip * 2 * nsub;
+    float *const ps = g.part_sec + (long long)clip * 2 * nsub;
+    unsigned *const arrive = tg.sync + 2 * clip, *const flag = arrive + 1;
+    int *const cur = tg.cur + 2 * clip;
+
+    // tile columns ≥ TWs and RT columns ≥ NAs are only read by the sliding windows of masked outputs: zero once (and after a refinement)
+    auto zero_padding = [&]() {
+        for (int r = wave; r < NAs; r += NW)
+            for (int c = TWs + lane; c < tg.pitchA; c += 64) A[r * tg.pitchA + c] = 0.f;
+        for (int x = wave; x < m2; x += NW)
+            for (int c = NAs + lane; c < tg.pitchV; c += 64) Vs[x * tg.pitchV + c] = f2{0.f, 0.f};
+    };
+    zero_padding();
+
+    int g1 = g.guesses[2 * clip], g2 = g.guesses[2 * clip + 1];
+    for (int k = 0; k < tg.chain_len; ++k) {
+        const long long fidx = tg.chain_len > 1 ? (long long)clip * tg.chain_len + k : (g.frame_index ? g.frame_index[clip] : clip);
+        const uint8_t *__restrict__ frame = g.frames + fidx * g.frame_stride;
+        const int wi0 = g1 - g.r1 - 1 - hw, wj0 = g2 - g.r2 - 1 - hw; // the full window's tile origin
+        const int ti0 = wi0 + sy, tj0 = wj0 + sx;                     // this sub-window's
+        // ---- DC level of the FULL window (the fused kernel's 32×32 sample grid) and staging of the sub-window's tile: the
+        // thread's sample and its first SU dwords are requested together (see dog_fused.hpp) ----
+        {
+            constexpr int SU = 4;
+            const int q = tid & ((1 << tg.cshift) - 1), sr0 = tid >> tg.cshift, srstep = NT >> tg.cshift;
+            const int c0 = 4 * q, gj0 = tj0 + c0, gj0c = min(max(gj0, 0), g.fw - 4);
+            const uint8_t *colp = frame + gj0c;
+            auto load_batch = [&](int r0, uint32_t (&v)[SU]) {
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int gi = ti0 + r0 + u * srstep;
+                    __builtin_memcpy(&v[u], colp + (long long)min(max(gi, 0), g.fh - 1) * g.row_stride, 4);
+                }
+            };
+            int samp;
+            {
+                const int si = wi0 + (int)(((long long)(tid >> 5) * tg.NA) >> 5), sj = wj0 + (int)(((long long)(tid & 31) * tg.TWin) >> 5);
+                samp = frame[(long long)min(max(si, 0), g.fh - 1) * g.row_stride + min(max(sj, 0), g.fw - 1)];
+                if (!(si >= 0 && si < g.fh && sj >= 0 && sj < g.fw)) samp = g.fill;
+            }
+            uint32_t v[SU];
+            load_batch(sr0, v);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) samp += __shfl_xor(samp, off, 64);
+            if (lane == 0) s_sum[wave] = samp;
+            __syncthreads();
+            int total = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) total += s_sum[w];
+            const int dc = dc_from_sum(total, g.fill);
+            for (int r0 = sr0; r0 < NAs; r0 += srstep * SU) {
+                if (r0 != sr0) load_batch(r0, v);
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int r = r0 + u * srstep, gi = ti0 + r;
+                    const bool rowok = gi >= 0 && gi < g.fh;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int gj = gj0 + i;
+                        const int px = (rowok && gj >= 0 && gj < g.fw) ? (int)((v[u] >> (8 * ((gj - gj0c) & 3))) & 0xffu) : g.fill;
+                        if (c0 + i < TWs && r < NAs) A[r * tg.pitchA + c0 + i] = (float)(px - dc);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- row pass → RT[x][a] ----
+        {
+            const int ngx = (m2 + tg.pr - 1) / tg.pr, ntask = NAs * ngx;
+            auto run = [&](auto Pc) {
+                constexpr int PR = decltype(Pc)::value;
+                for (int task = tid; task < ntask; task += NT) {
+                    const int gx = task / NAs, a = task - gx * NAs, xb = gx * PR;
+                    f2 acc[PR];
+                    fused_row_task<PR, U>(A + a * tg.pitchA + xb, L, trow, acc);
+#pragma unroll
+                    for (int o = 0; o < PR; ++o)
+                        if (xb + o < m2) Vs[(xb + o) * tg.pitchV + a] = acc[o];
+                }
+            };
+            switch (tg.pr) {
+            case 3: run(std::integral_constant<int, 3>{}); break;
+            case 4: run(std::integral_constant<int, 4>{}); break;
+            case 5: run(std::integral_constant<int, 5>{}); break;
+            case 6: run(std::integral_constant<int, 6>{}); break;
+            default: run(std::integral_constant<int, 8>{}); break;
+            }
+        }
+        __syncthreads();
+        // ---- column pass + peak (indices: the full window's column-major indices) ----
+        Peak pk;
+        peak_init(pk);
+        {
+            const int ngy = (m1 + tg.pc - 1) / tg.pc, ntask = m2 * ngy;
+            auto run = [&](auto Pc) {
+                constexpr int PC = decltype(Pc)::value;
+                for (int task = tid; task < ntask; task += NT) {
+                    const int gy = task / m2, x = task - gy * m2, yb = gy * PC;
+                    f2 acc[PC];
+                    fused_col_task<PC, U>(Vs + x * tg.pitchV + yb, L, tcol, acc);
+#pragma unroll
+                    for (int o = 0; o < PC; ++o) {
+                        const int y = yb + o;
+                        if (y < m1) {
+                            const float v = acc[o].x + acc[o].y;
+                            const int lin = (sx + x) * g.n1 + sy + y;
+                            if (RESP) g.resp[(long long)clip * g.n1 * g.n2 + lin] = v;
+                            peak_push(pk, v, lin);
+                        }
+                    }
+                }
+            };
+            switch (tg.pc) {
+            case 2: run(std::integral_constant<int, 2>{}); break;
+            case 3: run(std::integral_constant<int, 3>{}); break;
+            case 4: run(std::integral_constant<int, 4>{}); break;
+            case 6: run(std::integral_constant<int, 6>{}); break;
+            default: run(std::integral_constant<int, 8>{}); break;
+            }
+        }
+        peak_wave_reduce(pk);
+        if (lane == 0) { s_val[wave] = pk.best; s_idx[wave] = pk.idx; s_sec[wave] = pk.second; }
+        __syncthreads();
+        // ---- this sub-window's partial → memory (two sets of slots, by frame parity: a workgroup can be at most one
+        // frame ahead of the slowest reader).  Independent windows: the LAST arrival combines them.  Chains: EVERY
+        // workgroup waits for the arrival count and combines for itself — the same values in the same order give the same
+        // answer everywhere, two dependent memory round trips per frame instead of four (partials → guess → flag →
+        // guess); only the last arrival writes the answer out, and only a refinement (rare) goes through the frame flag. ----
+        const bool chain = k + 1 < tg.chain_len; // (the clip's last frame has no successor to wait for: the last arrival alone combines it)
+        const int par = (k & 1) * nsub;
+        const bool publish = tg.done_flag && clip == 0 && (tg.progress || k == tg.chain_len - 1);
+        int32_t *const o_ij = tg.out_ij + 2 * ((long long)clip * tg.chain_len + k);
+        if (wave == 0) {
+            peak_init(pk);
+            if (lane < NW) { pk.best = s_val[lane]; pk.idx = s_idx[lane]; pk.second = s_sec[lane]; }
+            peak_wave_reduce(pk, NW);
+            int last = 0;
+            if (lane == 0) {
+                __hip_atomic_store(&pv[par + s], pk.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&pi[par + s], pk.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ps[par + s], pk.second, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned target = (unsigned)(k + 1) * (unsigned)nsub;
+                const unsigned old = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                last = (old == target - 1u);
+                if (chain && !last)
+                    while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+            }
+            last = __shfl(last, 0, 64);
+            if (lane == 0) { s_last = last; s_refine = 0; }
+            if (last || chain) {
+                Peak w;
+                peak_init(w);
+                for (int sl = lane; sl < nsub; sl += 64) {
+                    const float v = __hip_atomic_load(&pv[par + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (sl < TILED_SLOT_CAP) s_pv[sl] = v;
+                    peak_merge(w, v, __hip_atomic_load(&pi[par + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                               __hip_atomic_load(&ps[par + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+                peak_wave_reduce(w);
+                if (lane == 0) {
+                    const int x = w.idx / g.n1, y = w.idx - x * g.n1;
+                    const int i = min(max(g1 - g.r1 + y, 1), g.fh);   // :60-61
+                    const int j = min(max(g2 - g.r2 + x, 1), g.fw);
+                    const bool rf = tg.rp && (w.best - w.second <= g.ex.T);
+                    s_refine = rf;
+                    s_max = w.best;
+                    s_idx[0] = i; // (the wave peaks have been consumed: the next guess travels through their slots)
+                    s_idx[1] = j;
+                    if (last) {
+                        if (k == 0) range_check(g.ex, g1, g2, hw, g.fh, g.fw);
+                        if (k == tg.chain_len - 1) { // nobody looks at the arrival count or the frame flag any more: zero for the next launch
+                            __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        if (rf) {
+                            atomicAdd(g.ex.stat, 1ull);
+                        } else {
+                            o_ij[0] = i;
+                            o_ij[1] = j;
+                            if (publish) {
+                                __threadfence_system();
+                                __hip_atomic_store(tg.done_flag, tg.progress ? k + 1 : tg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (s_refine) {
+            if (s_last) { // a near-tie: the reference's own arithmetic decides (dog_exact.hpp); this workgroup's LDS is the scratch
+                const refine_params_ptr rp = (refine_params_ptr)(unsigned long long)tg.rp;
+                RefineCtx c;
+                c.trow = trow;
+                c.tcol = tcol;
+                c.K = (k64_ptr)(unsigned long long)rp->K64;
+                c.g64 = (k64_ptr)(unsigned long long)rp->g64;
+                c.dir = rp->dir;
+                c.T64 = rp->T64;
+                c.T = g.ex.T;
+                c.cbw = tg.ref_cbw;
+                c.tile_rows = tg.ref_rows;
+                c.lds = smem;
+                const float thr = s_max - g.ex.T;
+                const bool slots_ok = nsub <= TILED_SLOT_CAP;
+                auto may = [&](int x0, int x1) { // sub-window (s1, s2) covers window columns [s2·sn2, s2·sn2 + sn2)
+                    if (!slots_ok) return true;
+                    for (int c2 = x0 / tg.sn2; c2 <= (x1 - 1) / tg.sn2 && c2 < tg.ns2; ++c2)
+                        for (int c1 = 0; c1 < tg.ns1; ++c1)
+                            if (s_pv[c2 * tg.ns1 + c1] >= thr) return true;
+                    return false;
+                };
+                const int idx = refine_window<4>(NT, g, frame, g1, g2, s_max, c, may);
+                if (tid == 0) {
+                    const int x = idx / g.n1, y = idx - x * g.n1;
+                    const int i = min(max(g1 - g.r1 + y, 1), g.fh);
+                    const int j = min(max(g2 - g.r2 + x, 1), g.fw);
+                    o_ij[0] = i;
+                    o_ij[1] = j;
+                    __hip_atomic_store(&cur[0], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&cur[1], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (publish) {
+                        __threadfence_system();
+                        __hip_atomic_store(tg.done_flag, tg.progress ? k + 1 : tg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    __hip_atomic_store(flag, k + 1 < tg.chain_len ? (unsigned)(k + 1) : 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); // (0 again after the last frame)
+                }
+                __syncthreads();
+                if (k + 1 < tg.chain_len) zero_padding();
+            }
+            if (k + 1 < tg.chain_len) { // the refined answer is the next guess (:167): it comes through the frame flag
+                if (tid == 0) {
+                    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(k + 1)) __builtin_amdgcn_s_sleep(1);
+                    s_idx[0] = __hip_atomic_load(&cur[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_idx[1] = __hip_atomic_load(&cur[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+            }
+        }
+        if (k + 1 < tg.chain_len) { // :167
+            g1 = s_idx[0];
+            g2 = s_idx[1];
+            __syncthreads();
+        }
+    }
+}
+
+} // namespace pdog

@@ -12,6 +12,7 @@
 #include "dog_fused.hpp"
 #include "dog_exact.hpp"
 #include "dog_coop.hpp"
+#include "dog_tiled.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -60,6 +61,9 @@ struct Switches {
     bool host_copy = false, host_sync = false, host_trace = false, twopass_4l = false, hpass16 = false;
     bool ingest_no_nt = false, ingest_trace = false, fused_diag = false;
     bool no_exact = false;                // PDOG_NO_EXACT: trackers start with exact mode off (A/B of its cost)
+    bool no_tiled = false;                // PDOG_NO_TILED: single large windows stay on the two-pass launches (A/B of the tiled kernel)
+    int tiled_sub = 0;                    // PDOG_TILED_SUB: sub-window edge of the tiled kernel (0: chosen per geometry)
+    int tiled_batch = 2;                  // PDOG_TILED_BATCH: windows per batch up to which the tiled kernel is used
     bool coop = false;                    // PDOG_COOP: single-clip chains of large windows as ONE cooperative launch (dog_coop.hpp; measured slower
                                           // than the three stream-ordered launches per frame it replaces, so off by default)
     size_t scratch_cap = (size_t)6 << 30; // HBM scratch of the two-pass intermediate; larger batches go in chunks
@@ -83,6 +87,9 @@ Switches read_switches()
     w.fused_diag = on("PDOG_FUSED_DIAG");
     w.no_exact = on("PDOG_NO_EXACT");
     w.coop = on("PDOG_COOP");
+    w.no_tiled = on("PDOG_NO_TILED");
+    if (const char *e = std::getenv("PDOG_TILED_SUB")) w.tiled_sub = std::max(0, std::min(96, std::atoi(e)));
+    if (const char *e = std::getenv("PDOG_TILED_BATCH")) w.tiled_batch = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("PDOG_SCRATCH_MB")) w.scratch_cap = (size_t)std::max(1, std::atoi(e)) << 20;
     if (const char *e = std::getenv("PDOG_MAP_MB")) w.map_cap = (size_t)std::max(0, std::atoi(e)) << 20;
     if (const char *e = std::getenv("PDOG_FUSED_P")) {
@@ -235,6 +242,13 @@ struct pdog_tracker {
     bool fused_ok = false;         // the window's tile fits in LDS: the fused kernel takes small batches and short chains
     int hp_rows = HP_ROWS;         // RT rows (window columns) per column-pass workgroup: 16 (P = 13) or 8 (P = 7)
     int32_t *d_chain_tmp = nullptr; // [2][n_clips][2]: current guesses / step results of multi-clip chains
+    // tiled kernel (dog_tiled.hpp): one large window cut into sub-windows, a workgroup each, one launch per batch / clip
+    bool tiled_ok = false;
+    int tiled_sn1 = 0, tiled_sn2 = 0, tiled_ns1 = 0, tiled_ns2 = 0, tiled_pr = 0, tiled_pc = 0, tiled_cshift = 0;
+    int tiled_ref_cbw = 1, tiled_ref_rows = 8, tiled_resident = 0; // refinement scratch geometry; workgroups the device keeps resident
+    size_t tiled_lds = 0;
+    int *d_tiled_ctl = nullptr;    // [cap][4]: current guess (2), partial arrivals, frame flag
+    int tiled_ctl_cap = 0;
     int *d_coop_cur = nullptr;     // [2] current guess of the cooperative single-clip chain, then 3 words of barrier state
     int coop_grid = -1;            // workgroups of the cooperative chain kernel (0: not available for this tracker; -1: not determined yet)
     int chain_tmp_cap = 0;
@@ -326,6 +340,154 @@ size_t fused_total_lds(const pdog_tracker *t)
     return std::max(fused_lds_bytes(t->n1, t->n2, t->L), refine_lds_bytes(t->n1, t->L, t->fused_ref_cbw, t->fused_ref_rows));
 }
 
+int ensure_capacity(pdog_tracker *t, int n);
+ExactCtl exact_ctl(const pdog_tracker *t);
+
+// Outputs per task of the fused / tiled kernels: fewest rounds of 1024 tasks, then least work per task (≈ P outputs + a fixed cost)
+int pick_outputs_per_task(int lines, int nout, std::initializer_list<int> ps, double fixed)
+{
+    int best = 0;
+    double best_cost = 0;
+    for (int p : ps) {
+        const long long tasks = (long long)lines * ((nout + p - 1) / p);
+        const double cost = (double)((tasks + FUSED_NT - 1) / FUSED_NT) * (p + fixed);
+        if (!best || cost < best_cost) { best = p; best_cost = cost; }
+    }
+    return best;
+}
+
+// Tiled kernel (dog_tiled.hpp): windows too large for the fused kernel, cut into sub-windows of ≈48 rows/columns (a
+// 257×257 window: 6×6 of 43×43, each a tile of 107×107 like the default 45×45 window of the fused kernel).
+int setup_tiled(pdog_tracker *t)
+{
+    t->tiled_ok = false;
+    if (t->fused_ok || t->sw.no_tiled || t->fw < 4) return PDOG_OK;
+    // Sub-window edge: ≈32 measured best for a 257×257 window (81 workgroups: 13.9 µs per frame; 48: 15.3), but beyond
+    // ≈128 workgroups the partial exchange costs more than smaller tiles save (513×513: 121 workgroups of 47 → 17.8 µs,
+    // 169 of 40 → 21.9); long kernels need smaller sub-windows for their halo to fit LDS.
+    int sn1 = 0, sn2 = 0, ns1 = 0, ns2 = 0;
+    size_t need = 0;
+    bool found = false;
+    const int user = t->sw.tiled_sub;
+    for (int target : {32, 40, 48, 56, 64, 24, 16}) {
+        if (user) target = user;
+        ns1 = (t->n1 + target - 1) / target;
+        ns2 = (t->n2 + target - 1) / target;
+        sn1 = (t->n1 + ns1 - 1) / ns1;
+        sn2 = (t->n2 + ns2 - 1) / ns2;
+        ns1 = (t->n1 + sn1 - 1) / sn1;
+        ns2 = (t->n2 + sn2 - 1) / sn2;
+        need = fused_lds_bytes(sn1, sn2, t->L);
+        const bool fits = need <= kMaxLds - 1024 && sn2 + t->L - 1 <= 4 * FUSED_NT && (long long)ns1 * ns2 <= (target >= 32 && !user ? 128 : TILED_SLOT_CAP);
+        if (fits) { found = true; break; }
+        if (user) break;
+    }
+    if (!found) return PDOG_OK;
+    // the refinement's scratch is the kernel's own LDS: at least its smallest form must fit; then the widest block that does
+    const size_t base = std::max(need, refine_lds_bytes(t->n1, t->L, 1, 8));
+    if (base > kMaxLds - 1024) return PDOG_OK;
+    const int NA = t->n1 + t->L - 1;
+    t->tiled_ref_cbw = 1;
+    t->tiled_ref_rows = 8;
+    for (int cbw = std::min(t->n2, t->ref_cbw); cbw >= 1; --cbw) {
+        const size_t fixed_r = refine_lds_bytes(t->n1, t->L, cbw, 0);
+        if (fixed_r + (size_t)8 * refine_tile_pitch(cbw, t->L) > base) continue;
+        t->tiled_ref_cbw = cbw;
+        t->tiled_ref_rows = (int)std::min<size_t>((size_t)NA, (base - fixed_r) / (size_t)refine_tile_pitch(cbw, t->L));
+        while (t->tiled_ref_rows > 8 && refine_lds_bytes(t->n1, t->L, cbw, t->tiled_ref_rows) > base) --t->tiled_ref_rows;
+        break;
+    }
+    t->tiled_sn1 = sn1; t->tiled_sn2 = sn2; t->tiled_ns1 = ns1; t->tiled_ns2 = ns2;
+    t->tiled_lds = base;
+    t->tiled_cshift = 0;
+    while ((1 << t->tiled_cshift) < (sn2 + t->L - 1 + 3) / 4) ++t->tiled_cshift;
+    t->tiled_pr = pick_outputs_per_task(sn1 + t->L - 1, sn2, {3, 4, 5, 6, 8}, 2.0);
+    t->tiled_pc = pick_outputs_per_task(sn2, sn1, {2, 3, 4, 6, 8}, 1.5);
+    for (const void *f : {(const void *)dog_tiled_kernel<false>, (const void *)dog_tiled_kernel<true>}) {
+        if (int rc = raise_lds_limit(f, base)) return rc;
+    }
+    int per_cu = 0, cus = 0, coop = 0;
+    t->tiled_resident = 0; // chains need every workgroup of a clip resident at once: a cooperative launch, if the device has them
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, t->device) == hipSuccess && coop &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)dog_tiled_kernel<false>, FUSED_NT, base) == hipSuccess && per_cu >= 1 &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) == hipSuccess)
+        t->tiled_resident = per_cu * cus;
+    t->tiled_ok = true;
+    return PDOG_OK;
+}
+
+// n windows (chain_len = 1: independent; ordinary launch) or n clips of chain_len frames (cooperative launch: the
+// workgroups of a clip wait for each other's partials frame by frame).  *launched = false: not taken, the caller goes on.
+int launch_tiled(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride, const int32_t *d_frame_index,
+                 const int32_t *d_guesses, int n, int chain_len, int32_t *d_out_ij, float *d_out_resp, int FH, int FW,
+                 int32_t *d_done_flag, int32_t done_value, bool progress, bool *launched)
+{
+    *launched = false;
+    if (!t->tiled_ok || n < 1) return PDOG_OK;
+    const int nsub = t->tiled_ns1 * t->tiled_ns2;
+    if (chain_len > 1 && (long long)n * nsub > t->tiled_resident) return PDOG_OK;
+    if (t->cap_windows < n || t->tiled_ctl_cap < n) {
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        if (t->cap_windows < n) { if (int rc = ensure_capacity(t, n)) return rc; }
+        if (t->tiled_ctl_cap < n) {
+            if (t->d_tiled_ctl) (void)hipFree(t->d_tiled_ctl);
+            t->d_tiled_ctl = nullptr; t->tiled_ctl_cap = 0;
+            HIP_TRY(hipMalloc(&t->d_tiled_ctl, sizeof(int) * 4 * (size_t)n));
+            HIP_TRY(hipMemset(t->d_tiled_ctl, 0, sizeof(int) * 4 * (size_t)n)); // the kernel leaves its counters at zero
+            t->tiled_ctl_cap = n;
+        }
+    }
+    TiledGeo tg;
+    std::memset(&tg, 0, sizeof tg);
+    LaunchGeo &g = tg.g;
+    g.frames = d_frames;
+    g.frame_stride = frame_stride;
+    g.row_stride = row_stride;
+    g.frame_index = d_frame_index;
+    g.guesses = d_guesses;
+    g.resp = d_out_resp;
+    g.part_val = t->d_part_val;
+    g.part_idx = t->d_part_idx;
+    g.part_sec = t->d_part_sec;
+    g.part_mask = t->d_part_mask;
+    g.ex = exact_ctl(t);
+    g.fh = FH; g.fw = FW; g.r1 = t->r1; g.r2 = t->r2; g.n1 = t->n1; g.n2 = t->n2;
+    g.L = t->L; g.fill = t->fill; g.nstrips = nsub; g.nslots = nsub; g.n = n; g.nblocks = n * nsub;
+    tg.NA = t->n1 + t->L - 1;
+    tg.TWin = t->n2 + t->L - 1;
+    tg.sn1 = t->tiled_sn1; tg.sn2 = t->tiled_sn2; tg.ns1 = t->tiled_ns1; tg.ns2 = t->tiled_ns2;
+    tg.pitchA = fused_pitch_a(t->tiled_sn2, t->L);
+    tg.pitchV = fused_pitch_v(t->tiled_sn1, t->L);
+    tg.cshift = t->tiled_cshift;
+    tg.pr = t->tiled_pr;
+    tg.pc = t->tiled_pc;
+    tg.chain_len = chain_len;
+    tg.out_ij = d_out_ij;
+    tg.done_flag = d_done_flag;
+    tg.done_value = done_value;
+    tg.progress = progress ? 1 : 0;
+    tg.rp = t->exact ? t->d_rp : nullptr;
+    tg.ref_cbw = t->tiled_ref_cbw;
+    tg.ref_rows = t->tiled_ref_rows;
+    tg.cur = t->d_tiled_ctl;
+    tg.sync = reinterpret_cast<unsigned *>(t->d_tiled_ctl + 2 * (size_t)t->tiled_ctl_cap);
+    const void *fn = d_out_resp ? (const void *)dog_tiled_kernel<true> : (const void *)dog_tiled_kernel<false>;
+    const f2 *tr = t->d_taps_row, *tc = t->d_taps_col;
+    if (chain_len > 1) {
+        void *args[] = {(void *)&tg, (void *)&tr, (void *)&tc};
+        const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(n * nsub), dim3(FUSED_NT), args, (unsigned)t->tiled_lds, t->stream);
+        if (e != hipSuccess) { (void)hipGetLastError(); return PDOG_OK; } // refused: the caller's other paths
+    } else {
+        if (d_out_resp)
+            hipLaunchKernelGGL(dog_tiled_kernel<true>, dim3(n * nsub), dim3(FUSED_NT), t->tiled_lds, t->stream, tg, tr, tc);
+        else
+            hipLaunchKernelGGL(dog_tiled_kernel<false>, dim3(n * nsub), dim3(FUSED_NT), t->tiled_lds, t->stream, tg, tr, tc);
+        HIP_TRY(hipGetLastError());
+    }
+    *launched = true;
+    return PDOG_OK;
+}
+
 int choose_variant(pdog_tracker *t, int forced)
 {
     const Variant *best = nullptr;
@@ -373,6 +535,7 @@ int choose_variant(pdog_tracker *t, int forced)
             if (int rc = raise_lds_limit((const void *)fused_kernel_for(t->L, resp), fused_total_lds(t))) return rc;
         }
     }
+    if (int rc = setup_tiled(t)) return rc;
     if (best->fused) { t->nstrips = 1; return PDOG_OK; }
     {
         // The two-pass kernels spread one window over dozens of workgroups, so they win whenever the batch
@@ -438,6 +601,7 @@ int ensure_capacity(pdog_tracker *t, int n)
     for (int i = 0; i < kNumVariants; ++i)
         if (!kVariants[i].fused) max_strips = std::max(max_strips, (t->n2 + kVariants[i].tw() - 1) / kVariants[i].tw() + kThinMax);
     max_strips = std::max(max_strips, (t->n2 + 7) / 8);
+    if (t->tiled_ok) max_strips = std::max(max_strips, 2 * t->tiled_ns1 * t->tiled_ns2); // the tiled kernel's partials: two sets per window
     for (void *p : {(void *)t->d_part_val, (void *)t->d_part_idx, (void *)t->d_part_sec, (void *)t->d_part_mask})
         if (p) (void)hipFree(p);
     t->d_part_val = t->d_part_sec = nullptr;
@@ -463,7 +627,7 @@ fused_fn_t fused_kernel_for(int L, bool resp)
 // batch kernel).  A batch of fewer than ≈1000 strip-waves cannot fill 256 CUs × 8 waves with one wave per strip:
 // windows that fit in LDS then go to the fused kernel (one workgroup per window, one launch), larger ones to the
 // two-pass kernels (dozens of workgroups per window).  pdog_set_variant pins the tracker's kernel.
-constexpr int kPathFused = 300, kPathTwoPass = 200;
+constexpr int kPathFused = 300, kPathTwoPass = 200, kPathTiled = 400;
 int path_for_batch(const pdog_tracker *t, int n)
 {
     const Variant &v = *t->var;
@@ -471,6 +635,7 @@ int path_for_batch(const pdog_tracker *t, int n)
     if (t->forced_variant) return v.twopass ? kPathTwoPass : v.id;
     const bool few = v.twopass ? n <= 256 : (long long)n * (t->nstrips + (t->nthin ? 1 : 0)) < 1000;
     if (few && t->fused_ok) return kPathFused;
+    if (t->tiled_ok && n <= t->sw.tiled_batch) return kPathTiled; // one or two windows too large for the fused kernel: one launch (dog_tiled.hpp)
     if (v.twopass || (few && t->small_twopass)) return kPathTwoPass;
     return v.id;
 }
@@ -611,8 +776,18 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         return launch_fused(t, d_frames, frame_stride, row_stride, d_frame_index, d_guesses, n, 1, d_out_ij, d_out_resp, FH, FW,
                             d_done_flag, done_value);
     }
+    // one or a few windows too large for the fused kernel: the tiled kernel, one launch (dog_tiled.hpp)
+    if (path == kPathTiled) {
+        bool launched = false;
+        if (int rc = launch_tiled(t, d_frames, frame_stride, row_stride, d_frame_index, d_guesses, n, 1, d_out_ij, d_out_resp, FH, FW,
+                                  d_done_flag, done_value, false, &launched)) return rc;
+        if (launched) {
+            if (ticket_armed) *ticket_armed = d_done_flag != nullptr;
+            return PDOG_OK;
+        }
+    }
     // small batches: fewer than ≈1000 strip-waves cannot fill 256 CUs × 8 waves; the two-pass kernels can
-    if (path == kPathTwoPass) {
+    if (path == kPathTwoPass || path == kPathTiled) {
         const int hr = t->sw.hpass16 ? HP_ROWS : 8; // 8 RT rows per workgroup (32 KB LDS → 4 workgroups per CU): +3 % on cfg5 vs 16; env = tuning switch
         const int tp_slots = (t->n2 + hr - 1) / hr; // partial slots = hr-column blocks
         g.nstrips = tp_slots;
@@ -994,6 +1169,7 @@ int pdog_destroy(pdog_tracker *t)
     if (t->d_counter) (void)hipFree(t->d_counter);
     if (t->d_chain_tmp) (void)hipFree(t->d_chain_tmp);
     if (t->d_coop_cur) (void)hipFree(t->d_coop_cur);
+    if (t->d_tiled_ctl) (void)hipFree(t->d_tiled_ctl);
     if (t->h2d_stream) { (void)hipStreamSynchronize(t->h2d_stream); (void)hipStreamDestroy(t->h2d_stream); }
     for (int k = 0; k < pdog_tracker::kIngestSlots; ++k) {
         if (t->h_stage[k]) (void)hipHostFree(t->h_stage[k]);
@@ -1628,6 +1804,12 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
         int rc = ensure_capacity(t, n_clips);
         if (rc) return rc;
     }
+    if (n_clips == 1 && !t->forced_variant) { // the tiled kernel: one cooperative launch, every sub-window's workgroup resident for the clip
+        bool launched = false;
+        if (int rc = launch_tiled(t, d_frames, frame_stride, row_stride, nullptr, d_start_guesses, 1, n_frames, d_out_ij, nullptr, t->fh, t->fw,
+                                  nullptr, 0, false, &launched)) return rc;
+        if (launched) return PDOG_OK;
+    }
     if (n_clips == 1) {
         // one cooperative launch for the clip where it is available (windows beyond the fused kernel, any kernel the
         // two-pass path serves) …
@@ -1706,6 +1888,12 @@ extern "C" int pdog_detect_chain_progress(pdog_tracker *t, const uint8_t *d_fram
     if (t->cap_windows < 1) {
         HIP_TRY(hipStreamSynchronize(t->stream));
         if (int rc = ensure_capacity(t, 1)) return rc;
+    }
+    if (!t->forced_variant) { // the tiled kernel: the combining workgroup publishes k + 1 after every frame
+        bool launched = false;
+        if (int rc = launch_tiled(t, d_frames, frame_stride, row_stride, nullptr, t->d_small, 1, n_frames, d_out, nullptr, t->fh, t->fw, d_prog, 0, true,
+                                  &launched)) return rc;
+        if (launched) return PDOG_OK;
     }
     if (!t->forced_variant || t->var->twopass) { // one cooperative launch: workgroup 0 publishes k + 1 after every frame
         bool launched = false;

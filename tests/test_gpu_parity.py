@@ -772,9 +772,10 @@ def test_kernel_for_batch_reports_the_launch_time_switch(pt):
     assert bt.kernel_for_batch(1) == 100
     bt.close()
     bt = pt.BatchTracker(1080, 1920, 25, (256, 256), True, 128)
-    assert bt.kernel_for_batch(1) == 200 and bt.kernel_for_batch(64) == 200 and bt.kernel_for_batch(4096) == 100
+    # one or two windows too large for the fused kernel: the tiled kernel (a workgroup per sub-window, one launch)
+    assert bt.kernel_for_batch(1) == 400 and bt.kernel_for_batch(2) == 400 and bt.kernel_for_batch(64) == 200 and bt.kernel_for_batch(4096) == 100
     bt.close()
-    bt = pt.BatchTracker(1080, 1920, 120, (205, 205), True, 128)
+    bt = pt.BatchTracker(1080, 1920, 120, (205, 205), True, 128)   # l = 293: no sub-window's halo fits LDS
     assert bt.info().variant == 200 and bt.kernel_for_batch(1) == 200 and bt.kernel_for_batch(4096) == 200
     bt.close()
 
