@@ -7,15 +7,18 @@
 // three stream-ordered launches per frame (row pass, column pass, finish: ≈27 µs per 257×257 frame, ≈50 µs per host
 // functor call); one cooperative launch with grid barriers between the passes was slower still (dog_coop.hpp: a
 // frame is ≈12 dependent memory round trips).  Here a frame is: samples + tile (one round trip) → both passes in LDS →
-// one partial per sub-window → the last arrival combines → the next guess (one more round trip).  The price is the
-// halo: each sub-window runs its row pass over l − 1 extra tile rows (2× the row-pass work at 43×43 sub-windows,
-// l = 65) — irrelevant where latency, not throughput, is what a single clip sees.
+// one partial per sub-window → combine.  The price is the halo: each sub-window runs its row pass over l − 1 extra
+// tile rows (3× the row-pass work at 32×32 sub-windows, l = 65) — irrelevant where latency, not throughput, is what a
+// single clip sees.  Measured (MI355X, 1080p, l = 65): 257×257 chain 13.8 µs per frame (27.5 µs with the launches).
 //
 // Arithmetic per output: exactly the fused kernel's (same tasks, same tap order), with the DC level taken from the
 // FULL window's sample grid, so every sub-window subtracts the same level and flat regions tie exactly across
 // sub-window borders; indices are the full window's column-major indices, ties → the smallest (findmax, :59).
-// Chains (chain_len > 1) keep all workgroups of a clip resident and spinning on the clip's frame flag: the host
-// launches them cooperatively (co-residency guaranteed or refused).
+//
+// Who combines.  Independent windows (chain_len = 1; an ordinary launch, any number of workgroups): the workgroup whose
+// partial arrives LAST.  Clips (chain_len > 1; a cooperative launch — every workgroup of a clip must be resident,
+// guaranteed or refused): every workgroup waits for the frame's arrival count and combines for itself, see the frame
+// loop.  The arrival count and the frame flag are zero when a launch ends, as they were when it started.
 #pragma once
 #include "dog_fused.hpp"
 
