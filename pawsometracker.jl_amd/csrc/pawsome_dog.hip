@@ -63,6 +63,8 @@ struct Switches {
     bool no_exact = false;                // PDOG_NO_EXACT: trackers start with exact mode off (A/B of its cost)
     bool no_tiled = false;                // PDOG_NO_TILED: single large windows stay on the two-pass launches (A/B of the tiled kernel)
     int tiled_sub = 0;                    // PDOG_TILED_SUB: sub-window edge of the tiled kernel (0: chosen per geometry)
+    int tp_ph1 = 0, tp_php = 0;           // PDOG_TP_P=ph1,php: outputs per task of the two-pass kernels (0: per geometry)
+    int hp_u = 8;                         // PDOG_HP_U: taps per block of the two-pass column pass (8 or 16)
     int tiled_batch = 2;                  // PDOG_TILED_BATCH: windows per batch up to which the tiled kernel is used
     bool coop = false;                    // PDOG_COOP: single-clip chains of large windows as ONE cooperative launch (dog_coop.hpp; measured slower
                                           // than the three stream-ordered launches per frame it replaces, so off by default)
@@ -90,6 +92,11 @@ Switches read_switches()
     w.no_tiled = on("PDOG_NO_TILED");
     if (const char *e = std::getenv("PDOG_TILED_SUB")) w.tiled_sub = std::max(0, std::min(96, std::atoi(e)));
     if (const char *e = std::getenv("PDOG_TILED_BATCH")) w.tiled_batch = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("PDOG_HP_U")) w.hp_u = std::atoi(e) == 16 ? 16 : 8;
+    if (const char *e = std::getenv("PDOG_TP_P")) {
+        int a = 0, b = 0;
+        if (std::sscanf(e, "%d,%d", &a, &b) == 2 && (a == 5 || a == 7 || a == 9 || a == 11 || a == 13 || a == 17) && (b == 5 || b == 7 || b == 9 || b == 13)) { w.tp_ph1 = a; w.tp_php = b; }
+    }
     if (const char *e = std::getenv("PDOG_SCRATCH_MB")) w.scratch_cap = (size_t)std::max(1, std::atoi(e)) << 20;
     if (const char *e = std::getenv("PDOG_MAP_MB")) w.map_cap = (size_t)std::max(0, std::atoi(e)) << 20;
     if (const char *e = std::getenv("PDOG_FUSED_P")) {
@@ -242,6 +249,7 @@ struct pdog_tracker {
     bool fused_ok = false;         // the window's tile fits in LDS: the fused kernel takes small batches and short chains
     int hp_rows = HP_ROWS;         // RT rows (window columns) per column-pass workgroup: 16 (P = 13) or 8 (P = 7)
     int32_t *d_chain_tmp = nullptr; // [2][n_clips][2]: current guesses / step results of multi-clip chains
+    int tp_ph1 = 13, tp_php = 7;   // outputs per task of the two-pass row / column pass (pick_twopass_p)
     // tiled kernel (dog_tiled.hpp): one large window cut into sub-windows, a workgroup each, one launch per batch / clip
     bool tiled_ok = false;
     int tiled_sn1 = 0, tiled_sn2 = 0, tiled_ns1 = 0, tiled_ns2 = 0, tiled_pr = 0, tiled_pc = 0, tiled_cshift = 0;
@@ -311,8 +319,60 @@ fused_fn_t fused_kernel_for(int L, bool resp);
 
 // LDS row pitches of the two-pass kernels: the sliding windows (and their one-block prefetch) of the last,
 // partly masked group of 13 outputs must stay inside the zero-padded row.  nout outputs, l taps.
-int twopass_pitch(int nout, int L, int rows = HP_ROWS) { return (round_up(nout, rows == 8 ? 32 * 7 : 16 * 13) + L + 48) | 1; } // (l rounded up to a block of 16 taps + one block of prefetch)
+// `quantum` = outputs one round of a workgroup covers (groups × outputs per task); + l rounded up to a block of 16 taps + one block of prefetch
+int twopass_pitch_q(int nout, int L, int quantum) { return (round_up(nout, quantum) + L + 48) | 1; }
+int twopass_pitch(int nout, int L, int rows = HP_ROWS) { return twopass_pitch_q(nout, L, rows == 8 ? 32 * 7 : 16 * 13); } // the cooperative chain's fixed instances
 
+// Outputs per task (P) of the two-pass ROW pass, per geometry.  A workgroup covers 16 × P outputs per round: a 257-wide
+// window on P = 13 (208 per round) ran a second round 24 % full.  Measured per launch (4096 windows, same session):
+//   257 wide, l = 109:  P = 5 1.94 ms, 7 1.83, 9 1.84, 11 2.20, 13 2.39, 17 2.18   (96 VGPRs at P = 9, 155 at 13)
+//   205 wide, l = 293:  P = 5 4.35 ms, 7 4.17, 9 4.11, 11 4.61, 13 3.97            (13: one round, 98 % full)
+// ⇒ P = 9 unless P = 13 fills its rounds better.
+// COLUMN pass (32 × P outputs per round, 8 taps per block: 76 VGPRs against 125 with 16-tap blocks, −8 % on every config):
+//   257 tall, l = 109:  P = 5 2.13 ms, 7 2.36, 9 1.96, 13 2.37
+//   205 tall, l = 293:  P = 5 3.44 ms, 7 2.50, 9 2.57, 13 3.45
+// ⇒ P = 7 unless P = 9 fills its rounds better.
+typedef void (*tp_fn)(TwoPassGeo, const f2 *);
+tp_fn h1_kernel_for(int P, bool dcin)
+{
+    switch (P) {
+    case 5: return dcin ? (tp_fn)dog_h1_kernel<5, 8, true> : (tp_fn)dog_h1_kernel<5, 8, false>;
+    case 7: return dcin ? (tp_fn)dog_h1_kernel<7, 8, true> : (tp_fn)dog_h1_kernel<7, 8, false>;
+    case 9: return dcin ? (tp_fn)dog_h1_kernel<9, 8, true> : (tp_fn)dog_h1_kernel<9, 8, false>;
+    case 11: return dcin ? (tp_fn)dog_h1_kernel<11, 8, true> : (tp_fn)dog_h1_kernel<11, 8, false>;
+    case 17: return dcin ? (tp_fn)dog_h1_kernel<17, 8, true> : (tp_fn)dog_h1_kernel<17, 8, false>;
+    default: return dcin ? (tp_fn)dog_h1_kernel<13, 8, true> : (tp_fn)dog_h1_kernel<13, 8, false>;
+    }
+}
+tp_fn hpass8_kernel_for(int P, bool resp, bool fin, int U = 16)
+{
+#define PDOG_HP8(PP, UU) (fin ? (resp ? (tp_fn)dog_hpass_kernel<PP, UU, true, 8, true> : (tp_fn)dog_hpass_kernel<PP, UU, false, 8, true>) \
+                              : (resp ? (tp_fn)dog_hpass_kernel<PP, UU, true, 8, false> : (tp_fn)dog_hpass_kernel<PP, UU, false, 8, false>))
+    if (U == 8) {
+        switch (P) {
+        case 5: return PDOG_HP8(5, 8);
+        case 9: return PDOG_HP8(9, 8);
+        case 13: return PDOG_HP8(13, 8);
+        default: return PDOG_HP8(7, 8);
+        }
+    }
+    switch (P) {
+    case 5: return PDOG_HP8(5, 16);
+    case 9: return PDOG_HP8(9, 16);
+    default: return PDOG_HP8(7, 16);
+    }
+#undef PDOG_HP8
+}
+int pick_h1_outputs(int nout)
+{
+    auto fill = [&](int p) { return (double)nout / (double)(round_up(nout, 16 * p)); };
+    return fill(13) > fill(9) + 0.05 ? 13 : 9;
+}
+int pick_hpass_outputs(int nout)
+{
+    auto fill = [&](int p) { return (double)nout / (double)(round_up(nout, 32 * p)); };
+    return fill(9) > fill(7) + 0.05 ? 9 : 7;
+}
 // Exact mode's refinement (dog_exact.hpp) works on blocks of `cbw` window columns whose row-pass result (two doubles
 // per element in the Float64 stage) fits ≈24 KB of LDS; the block's pixels go through an LDS tile — all n1 + l − 1 rows
 // resident when that fits 100 KB in total (l ≲ 150: a candidate's exact chain then reads LDS), otherwise ≈24 KB slices.
@@ -488,6 +548,11 @@ int launch_tiled(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     return PDOG_OK;
 }
 
+// Longest kernel the roll instances serve by default.  The l = 101 / 105 instances spill in their loop and measured 3.95 /
+// 4.15 ms per 4096 windows of 257×257 against 3.54 / 3.65 ms for the two-pass kernels (since those run register-ring
+// windows and per-geometry task sizes); they stay selectable (variants 201, 205) and serve the persistent multi-clip chain.
+constexpr int kRollBatchLmax = 97;
+
 int choose_variant(pdog_tracker *t, int forced)
 {
     const Variant *best = nullptr;
@@ -501,11 +566,11 @@ int choose_variant(pdog_tracker *t, int forced)
         }
         if (v.LT != 0 && v.LT != t->L) continue;
         if (v.lds(t->L) > kMaxLds) continue;
-        if (forced < 0 && t->L > ROLL_LMAX && !v.twopass) continue; // long kernels: two-pass path (measured 1.7× the ring kernel at l = 293)
+        if (forced < 0 && t->L > kRollBatchLmax && !v.twopass) continue; // long kernels: two-pass path (measured 1.7× the ring kernel at l = 293)
         if (v.twopass) {
             const size_t hl = (size_t)HP_ROWS * twopass_pitch(t->n1, t->L) * sizeof(f2);
             if (hl > kMaxLds - 1024) continue;
-            if (forced < 0 && t->L <= ROLL_LMAX) continue; // the ring/roll kernels win where a roll instance exists
+            if (forced < 0 && t->L <= kRollBatchLmax) continue; // the ring/roll kernels win where a spill-free roll instance exists
             if (!best || forced >= 0) { best = &v; best_cost = 0.0; }
             continue;
         }
@@ -541,37 +606,26 @@ int choose_variant(pdog_tracker *t, int forced)
         // The two-pass kernels spread one window over dozens of workgroups, so they win whenever the batch
         // cannot fill the GPU with one wave per strip (single-frame tracking: 36 µs vs 144 µs for one
         // 257×257 window).  Set them up whenever their LDS tiles fit.
+        t->tp_ph1 = t->sw.tp_ph1 ? t->sw.tp_ph1 : pick_h1_outputs(t->n2);
+        t->tp_php = t->sw.tp_php ? t->sw.tp_php : pick_hpass_outputs(t->n1);
         const size_t hl = (size_t)HP_ROWS * twopass_pitch(t->n1, t->L) * sizeof(f2);
-        const size_t h1l = (size_t)HP_ROWS * twopass_pitch(t->n2, t->L) * sizeof(float);
-        if (hl <= kMaxLds - 1024 && h1l <= kMaxLds - 1024) {
+        const size_t h1l = (size_t)HP_ROWS * twopass_pitch_q(t->n2, t->L, 16 * t->tp_ph1) * sizeof(float);
+        const size_t hl8 = (size_t)8 * twopass_pitch_q(t->n1, t->L, 32 * t->tp_php) * sizeof(f2);
+        if (hl <= kMaxLds - 1024 && h1l <= kMaxLds - 1024 && hl8 <= kMaxLds - 1024) {
             for (const void *f : {(const void *)dog_hpass_kernel<13, 16, false>, (const void *)dog_hpass_kernel<13, 16, true>}) {
                 if (int rc = raise_lds_limit(f, hl)) return rc;
             }
-            const size_t hl8 = (size_t)8 * twopass_pitch(t->n1, t->L, 8) * sizeof(f2);
-            for (const void *f : {(const void *)dog_hpass_kernel<7, 16, false, 8>, (const void *)dog_hpass_kernel<7, 16, true, 8>,
-                                  (const void *)dog_hpass_kernel<7, 16, false, 8, true>, (const void *)dog_hpass_kernel<7, 16, true, 8, true>}) {
-                if (int rc = raise_lds_limit(f, hl8)) return rc;
-            }
-            for (const void *f : {(const void *)dog_h1_kernel<13, 8>, (const void *)dog_h1_kernel<13, 8, true>}) {
-                if (int rc = raise_lds_limit(f, h1l)) return rc;
-            }
+            for (bool resp : {false, true})
+                for (bool fin : {false, true})
+                    if (int rc = raise_lds_limit((const void *)hpass8_kernel_for(t->tp_php, resp, fin, t->sw.hp_u), hl8)) return rc;
+            for (bool dcin : {false, true})
+                if (int rc = raise_lds_limit((const void *)h1_kernel_for(t->tp_ph1, dcin), h1l)) return rc;
             t->small_twopass = true;
         }
     }
     if (best->twopass) {
         t->nstrips = (t->n2 + HP_ROWS - 1) / HP_ROWS; // partial slots = 16-column blocks
-        const int hl = (int)((size_t)HP_ROWS * twopass_pitch(t->n1, t->L) * sizeof(f2));
-        const int h1l = (int)((size_t)HP_ROWS * twopass_pitch(t->n2, t->L) * sizeof(float));
-        for (const void *f : {(const void *)dog_hpass_kernel<13, 16, false>, (const void *)dog_hpass_kernel<13, 16, true>}) {
-            if (int rc = raise_lds_limit(f, (size_t)hl)) return rc;
-        }
-        for (const void *f : {(const void *)dog_hpass_kernel<7, 16, false, 8>, (const void *)dog_hpass_kernel<7, 16, true, 8>,
-                              (const void *)dog_hpass_kernel<7, 16, false, 8, true>, (const void *)dog_hpass_kernel<7, 16, true, 8, true>}) {
-            if (int rc = raise_lds_limit(f, (size_t)8 * twopass_pitch(t->n1, t->L, 8) * sizeof(f2))) return rc;
-        }
-        for (const void *f : {(const void *)dog_h1_kernel<13, 8>, (const void *)dog_h1_kernel<13, 8, true>}) {
-            if (int rc = raise_lds_limit(f, (size_t)h1l)) return rc;
-        }
+        if (!t->small_twopass) return fail(PDOG_E_ARG, "two-pass kernels: the window's rows do not fit LDS");
         return PDOG_OK;
     }
     if (best->roll && best->thin && t->n2 > best->tw()) {
@@ -817,8 +871,8 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         tg.NA = t->n1 + t->L - 1;
         tg.h1blocks_per_win = (tg.NA + HP_ROWS - 1) / HP_ROWS;
         tg.hblocks_per_win = tp_slots;
-        tg.pitchA = twopass_pitch(t->n2, t->L);
-        tg.pitchV = twopass_pitch(t->n1, t->L, hr);
+        tg.pitchA = twopass_pitch_q(t->n2, t->L, 16 * t->tp_ph1);
+        tg.pitchV = hr == 8 ? twopass_pitch_q(t->n1, t->L, 32 * t->tp_php) : twopass_pitch(t->n1, t->L, hr);
         const size_t per_win = (size_t)t->n2 * tg.NA * sizeof(f2);
         const size_t cap = t->sw.scratch_cap; // HBM scratch for the transposed intermediate; larger batches go in chunks
         const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, cap / per_win));
@@ -855,12 +909,9 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         if (lowlat && t->exact) {
             tg.win0 = 0;
             if (ticket_armed) *ticket_armed = d_done_flag != nullptr;
-            hipLaunchKernelGGL((dog_h1_kernel<13, 8, true>), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
+            hipLaunchKernelGGL(h1_kernel_for(t->tp_ph1, true), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
             HIP_TRY(hipGetLastError());
-            if (want_resp)
-                hipLaunchKernelGGL((dog_hpass_kernel<7, 16, true, 8>), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
-            else
-                hipLaunchKernelGGL((dog_hpass_kernel<7, 16, false, 8>), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
+            hipLaunchKernelGGL(hpass8_kernel_for(t->tp_php, want_resp, false, t->sw.hp_u), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             HIP_TRY(hipGetLastError());
             return launch_finish(t, g, hr, 1 << 30, d_out_ij, d_done_flag, done_value, false, t->exact ? map : nullptr);
         }
@@ -874,12 +925,9 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
             tg.done_flag = d_done_flag;
             tg.done_value = done_value;
             if (ticket_armed) *ticket_armed = d_done_flag != nullptr;
-            hipLaunchKernelGGL((dog_h1_kernel<13, 8, true>), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
+            hipLaunchKernelGGL(h1_kernel_for(t->tp_ph1, true), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
             HIP_TRY(hipGetLastError());
-            if (want_resp)
-                hipLaunchKernelGGL((dog_hpass_kernel<7, 16, true, 8, true>), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
-            else
-                hipLaunchKernelGGL((dog_hpass_kernel<7, 16, false, 8, true>), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
+            hipLaunchKernelGGL(hpass8_kernel_for(t->tp_php, want_resp, true, t->sw.hp_u), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             HIP_TRY(hipGetLastError());
             return PDOG_OK;
         }
@@ -888,13 +936,10 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         for (int w0 = 0; w0 < n; w0 += chunk) {
             const int nw = std::min(chunk, n - w0);
             tg.win0 = w0;
-            hipLaunchKernelGGL((dog_h1_kernel<13, 8>), dim3(nw * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
+            hipLaunchKernelGGL(h1_kernel_for(t->tp_ph1, false), dim3(nw * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
             HIP_TRY(hipGetLastError());
             if (hr == 8) {
-                if (want_resp)
-                    hipLaunchKernelGGL((dog_hpass_kernel<7, 16, true, 8>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
-                else
-                    hipLaunchKernelGGL((dog_hpass_kernel<7, 16, false, 8>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
+                hipLaunchKernelGGL(hpass8_kernel_for(t->tp_php, want_resp, false, t->sw.hp_u), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             } else if (want_resp)
                 hipLaunchKernelGGL((dog_hpass_kernel<13, 16, true>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             else

@@ -892,8 +892,10 @@ def test_every_roll_instance_pinned(pt, oracle, l):
         frames, guesses, _ = synth.make_batch(n, h, w, max(2, int(tw)), radii, True, seed=int(rng.integers(1 << 30)), noise=3)
         fill = oracle.mode_u8(frames[0])
         bt = pt.BatchTracker(h, w, tw, ws, True, fill)
-        vid = bt.info().variant
-        assert vid == (100 if l == 65 else 100 + l) and bt.info().kernel_len == l
+        vid = 100 if l == 65 else 100 + l
+        # up to l = 97 the roll instance is the tracker's batch kernel; at l = 101 / 105 (instances that spill in their
+        # loop) the two-pass kernels are faster since round 2 and are the default — the instances stay selectable
+        assert bt.info().variant == (vid if l <= 97 else 200) and bt.info().kernel_len == l
         bt.set_variant(vid)
         assert bt.kernel_for_batch(n) == vid
         got, resp = bt.detect(torch.from_numpy(frames).cuda(), torch.from_numpy(guesses).cuda(), want_resp=True)
