@@ -47,6 +47,9 @@ __host__ __device__ constexpr size_t fused_a_bytes(int n1, int n2, int L) { retu
 __host__ __device__ constexpr size_t fused_lds_bytes(int n1, int n2, int L) { return fused_a_bytes(n1, n2, L) + (size_t)n2 * fused_pitch_v(n1, L) * 8; }
 
 // PR outputs of one tile row: out[o] = Σ_k (g₊[k], g₋[k]) · in[o+k], symmetric pairs first (k ascending), centre last.
+// (The register-ring windows that removed the shifts from the two-pass kernels were measured here too: SLOWER — 10.8 →
+// 11.6 µs per 45×45 frame, 13.8 → 14.7 µs per 257×257 frame — under the 128-VGPR budget of a 1024-thread workgroup the three
+// unrolled blocks per trip spill, and five P instances of each task triple in code size.)
 // Runtime kernel length, blocks of U taps.  (Compile-time-l instances with the tap loop fully unrolled were
 // tried for l = 65: 400 SGPR + 300 VGPR spills under the 128-VGPR budget of a 1024-thread workgroup, 2× slower.)
 template <int P, int U>

@@ -61,6 +61,7 @@ struct Switches {
     bool host_copy = false, host_sync = false, host_trace = false, twopass_4l = false, hpass16 = false;
     bool ingest_no_nt = false, ingest_trace = false, fused_diag = false;
     bool no_exact = false;                // PDOG_NO_EXACT: trackers start with exact mode off (A/B of its cost)
+    bool tiled_force = false;             // PDOG_TILED_FORCE: experiment — the tiled kernel also for windows the fused kernel serves
     bool no_tiled = false;                // PDOG_NO_TILED: single large windows stay on the two-pass launches (A/B of the tiled kernel)
     int tiled_sub = 0;                    // PDOG_TILED_SUB: sub-window edge of the tiled kernel (0: chosen per geometry)
     int tp_ph1 = 0, tp_php = 0;           // PDOG_TP_P=ph1,php: outputs per task of the two-pass kernels (0: per geometry)
@@ -90,6 +91,7 @@ Switches read_switches()
     w.no_exact = on("PDOG_NO_EXACT");
     w.coop = on("PDOG_COOP");
     w.no_tiled = on("PDOG_NO_TILED");
+    w.tiled_force = on("PDOG_TILED_FORCE");
     if (const char *e = std::getenv("PDOG_TILED_SUB")) w.tiled_sub = std::max(0, std::min(96, std::atoi(e)));
     if (const char *e = std::getenv("PDOG_TILED_BATCH")) w.tiled_batch = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("PDOG_HP_U")) w.hp_u = std::atoi(e) == 16 ? 16 : 8;
@@ -421,7 +423,7 @@ int pick_outputs_per_task(int lines, int nout, std::initializer_list<int> ps, do
 int setup_tiled(pdog_tracker *t)
 {
     t->tiled_ok = false;
-    if (t->fused_ok || t->sw.no_tiled || t->fw < 4) return PDOG_OK;
+    if ((t->fused_ok && !t->sw.tiled_force) || t->sw.no_tiled || t->fw < 4) return PDOG_OK;
     // Sub-window edge: ≈32 measured best for a 257×257 window (81 workgroups: 13.9 µs per frame; 48: 15.3), but beyond
     // ≈128 workgroups the partial exchange costs more than smaller tiles save (513×513: 121 workgroups of 47 → 17.8 µs,
     // 169 of 40 → 21.9); long kernels need smaller sub-windows for their halo to fit LDS.
@@ -1804,6 +1806,12 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
     // batch that the two-pass kernels spread over many workgroups (21 µs vs 48 µs per frame, one 45×45 window).
     const bool persistent = v.roll && v.chain && chain_strips <= 8 &&
                             (t->forced_variant || !t->small_twopass || (long long)n_clips * chain_strips >= 1000);
+    if (t->sw.tiled_force && n_clips == 1 && !t->forced_variant) {
+        bool launched = false;
+        if (int rc = launch_tiled(t, d_frames, frame_stride, row_stride, nullptr, d_start_guesses, 1, n_frames, d_out_ij, nullptr, t->fh, t->fw,
+                                  nullptr, 0, false, &launched)) return rc;
+        if (launched) return PDOG_OK;
+    }
     if (v.fused || (!persistent && !t->forced_variant && t->fused_ok)) // one launch: a workgroup per clip loops over its frames
         return launch_fused(t, d_frames, frame_stride, row_stride, nullptr, d_start_guesses, n_clips, n_frames, d_out_ij, nullptr, t->fh, t->fw);
     if (persistent) {

@@ -4,7 +4,8 @@ import numpy as np, torch
 import pawsometracker_jl_amd as pt
 from oracle import synth
 h, w, tw, ws = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-f = synth.disc_frame(h, w, (h // 2 - 40, w // 2 + 60), tw, True)
+off = (40, 60) if ws > 120 else (ws // 5, ws // 4)
+f = synth.disc_frame(h, w, (h // 2 - off[0], w // 2 + off[1]), tw, True)
 nf = 256
 frames = torch.from_numpy(np.broadcast_to(f, (nf, h, w)).copy()).cuda()
 bt = pt.BatchTracker(h, w, tw, (ws, ws), True, 128)
