@@ -38,12 +38,12 @@ constexpr int COOP_HR = 8; // window columns per column-pass block (as the two-p
 // Grid barrier for workgroups the cooperative launch keeps resident: a monotonic arrival counter (zeroed by the host
 // before the launch), release on arrival, acquire spin until everyone of this round has arrived.  (HIP's
 // cooperative_groups grid sync measured ≈12 µs per barrier here — more than the three launches it was to replace.)
-__device__ __forceinline__ void coop_barrier(unsigned *ctr, unsigned target)
+__device__ __forceinline__ void coop_barrier(unsigned *ctr, unsigned target, const ExactCtl &x)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        (void)wait_counter(ctr, target, x);
     }
     __syncthreads();
 }
@@ -75,7 +75,7 @@ static __global__ __launch_bounds__(256) void dog_coop_chain_kernel(const CoopGe
             __syncthreads(); // the LDS tile is rewritten by the next block
         }
         __threadfence();
-        coop_barrier(bar, (unsigned)(k + 1) * G); // every RT row is there (and nothing stale of frame k − 1 in this CU's cache)
+        coop_barrier(bar, (unsigned)(k + 1) * G, g.ex); // every RT row is there (and nothing stale of frame k − 1 in this CU's cache)
         // ---- column pass + partial peaks ----
         for (int cb = blockIdx.x; cb < tg.hblocks_per_win; cb += G) {
             const Peak pk = hpass_block<7, 16, false, COOP_HR>(tg, taps_col, smem, 0, cb, 0);
@@ -150,7 +150,7 @@ static __global__ __launch_bounds__(256) void dog_coop_chain_kernel(const CoopGe
                 __hip_atomic_store(flag, (unsigned)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); // the next guess is out
             }
         } else if (tid == 0) {
-            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(k + 1)) __builtin_amdgcn_s_sleep(1);
+            (void)wait_counter(flag, (unsigned)(k + 1), g.ex);
         }
         __syncthreads();
     }

@@ -81,6 +81,21 @@ struct ExactCtl {
 // The reference's PaddedView extends radii + l past the frame (:45-46) and the filter reads radii + l÷2 around the
 // guess: a guess outside [−l÷2, sz + l÷2 + 1] raises BoundsError there.  Device-resident guesses cannot be checked
 // before the launch, so the kernels raise a flag that pdog_sync reports.
+// Bounded wait for a device-scope counter that other resident workgroups advance (dog_tiled.hpp, dog_coop.hpp): every wave
+// that waits reaches an exit — after ≈1 s without progress the wait gives up, raises the fault value 2 in the host-coherent
+// word (pdog_sync then reports PDOG_E_HIP) and the kernel runs on to its end with whatever it has.  Returns false on give-up.
+__device__ __forceinline__ bool wait_counter(const unsigned *ctr, unsigned target, const ExactCtl &x)
+{
+    for (unsigned spins = 0; __hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+        __builtin_amdgcn_s_sleep(1);
+        if (spins > (1u << 24)) {
+            if (x.range_err) __hip_atomic_store(x.range_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return false;
+        }
+    }
+    return true;
+}
+
 __device__ __forceinline__ void range_check(const ExactCtl &x, int g1, int g2, int hw, int fh, int fw)
 {
     if (x.range_err && (g1 < -hw || g1 > fh + hw + 1 || g2 < -hw || g2 > fw + hw + 1))

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
                 const unsigned old = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
                 last = (old == target - 1u);
                 if (chain && !last)
-                    while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+                    (void)wait_counter(arrive, target, g.ex);
             }
             last = __shfl(last, 0, 64);
             if (lane == 0) { s_last = last; s_refine = 0; }
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
             }
             if (k + 1 < tg.chain_len) { // the refined answer is the next guess (:167): it comes through the frame flag
                 if (tid == 0) {
-                    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(k + 1)) __builtin_amdgcn_s_sleep(1);
+                    (void)wait_counter(flag, (unsigned)(k + 1), g.ex);
                     s_idx[0] = __hip_atomic_load(&cur[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_idx[1] = __hip_atomic_load(&cur[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }

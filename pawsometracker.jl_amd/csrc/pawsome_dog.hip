@@ -1312,8 +1312,13 @@ int pdog_sync(pdog_tracker *t)
 {
     if (!t) return fail(PDOG_E_ARG, "pdog_sync: null tracker");
     HIP_TRY(hipStreamSynchronize(t->stream));
-    if (__atomic_load_n(&t->h_pinned[5], __ATOMIC_ACQUIRE)) { // raised by a kernel: a device-resident guess was out of range
+    if (const int32_t raised = __atomic_load_n(&t->h_pinned[5], __ATOMIC_ACQUIRE)) { // raised by a kernel
         __atomic_store_n(&t->h_pinned[5], 0, __ATOMIC_RELEASE);
+        if (raised == 2) { // a wait between resident workgroups gave up (wait_counter): the positions of that work are not valid
+            if (t->d_tiled_ctl) (void)hipMemset(t->d_tiled_ctl, 0, sizeof(int) * 4 * (size_t)t->tiled_ctl_cap);
+            return fail(PDOG_E_HIP, "pdog_sync: a kernel gave up waiting for its other workgroups (device-side watchdog); the results of the work just finished are not valid");
+        }
+        // a device-resident guess was out of range
         return fail(PDOG_E_RANGE, "pdog_sync: a guess of the work just finished lies outside the padded frame (reference: BoundsError, "
                                   "src/PawsomeTracker.jl:45-46); positions were computed with the fill value there");
     }

@@ -227,6 +227,7 @@ def test_cooperative_single_clip_chain(pt, oracle, monkeypatch):
             want.append(list(g))
         d_clip = torch.from_numpy(clip).cuda()
         monkeypatch.setenv("PDOG_COOP", "1")
+        monkeypatch.setenv("PDOG_NO_TILED", "1")     # (the default for such a clip is the tiled kernel, tests/test_gpu_tiled.py)
         for exact in (1, 2):
             if exact == 2 and tw == 120:
                 continue                         # every pixel through the dense chain at l = 293: minutes
@@ -241,6 +242,7 @@ def test_cooperative_single_clip_chain(pt, oracle, monkeypatch):
             cp.close()
             bt.close()
         monkeypatch.delenv("PDOG_COOP")
+        monkeypatch.delenv("PDOG_NO_TILED")
         bt = pt.BatchTracker(fh, fw, tw, ws, True, ot.fill)
         got = bt.detect_chain(d_clip, start)
         bt.sync()
