@@ -53,7 +53,8 @@ static __global__ __launch_bounds__(256) void dog_coop_chain_kernel(const CoopGe
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_refine, s_last;
-    __shared__ float s_max;
+    __shared__ float s_max, s_sec2;
+    __shared__ int s_idx2;
     const TwoPassGeo &tg = cg.tg;
     const LaunchGeo &g = tg.g;
     const int tid = threadIdx.x;
@@ -106,6 +107,8 @@ static __global__ __launch_bounds__(256) void dog_coop_chain_kernel(const CoopGe
                     if (rf) atomicAdd(g.ex.stat, 1ull);
                     s_refine = rf;
                     s_max = pk.best;
+                    s_sec2 = pk.second;
+                    s_idx2 = pk.idx;
                     const int x = pk.idx / g.n1, y = pk.idx - x * g.n1;
                     cg.cur[0] = min(max(g1 - g.r1 + y, 1), g.fh);   // :60-61 (overwritten below if refined)
                     cg.cur[1] = min(max(g2 - g.r2 + x, 1), g.fw);
@@ -122,6 +125,8 @@ static __global__ __launch_bounds__(256) void dog_coop_chain_kernel(const CoopGe
                 c.dir = rp->dir;
                 c.T64 = rp->T64;
                 c.T = g.ex.T;
+                c.second = s_sec2;
+                c.fp32_idx = s_idx2;
                 c.cbw = cg.ref_cbw;
                 c.tile_rows = cg.ref_rows;
                 c.lds = smem;

@@ -11,8 +11,11 @@
 //     column pass  one chain of 2l FMAs over terms bounded by Σ|ĉ±||R̂±| ≤ 2V/255:     ≤ 2l·u·2V/255
 //                  + the row errors times Σ|c±| = 1/255 each + the column taps' rounding 2u·V/255
 //     ⇒ δ = u·(V/255)·(6l + 4)·(1 + ε)  + the reference's own Float64 rounding (≤ l²·2⁻⁵³·2·V/255, negligible)
-// (any summation order, with or without the symmetric pre-add — so it covers every kernel family).  V = 255 is
-// used: δ(l = 65) = 2.35e-5 against a typical peak of 0.09 and a typical peak-to-neighbour gap of 4.7e-4.
+// (any summation order, with or without the symmetric pre-add — so it covers every kernel family).  The FLAG uses
+// V = 255: δ(l = 65) = 2.35e-5 against a typical peak of 0.09 and a typical peak-to-neighbour gap of 4.7e-4.  The
+// REFINEMENT of a flagged window may take the window's own V = max |pixel − dc| over its padded tile (refine_window,
+// `tighten`): δ is proportional to it, so a window of ±2-level noise (V ≈ 3) has an 85× smaller T — a handful of
+// candidates instead of thousands, or no near-tie at all (the flag is withdrawn and the FP32 argmax stands).
 //   1. Every main kernel also tracks the RUNNER-UP value of its window (Peak, dog_kernels.hpp).  If best − runner-up > 2δ
 //      the FP32 argmax is the reference's argmax (the true argmax p* has f(p*) ≥ F(p*) − δ ≥ F(p̂) − δ ≥ f(p̂) − 2δ,
 //      so it is p̂ itself) and nothing else happens: ≈99 % of blob windows.
@@ -155,7 +158,10 @@ struct RefineCtx {
     k64_ptr g64;         // [2][l]: the normalised Gaussians σ and √2σ in Float64
     double dir;          // direction, :42
     double T64;          // 2δ64
-    float T;             // 2δ
+    float T;             // 2δ for |pixel − dc| ≤ 255
+    float second;        // the window's FP32 runner-up value and the FP32 argmax (column-major index): with the window's own
+    int fp32_idx;        // |pixel − dc| bound the flag may turn out unnecessary (fp32_idx < 0: not supplied, never withdrawn)
+    int v_after = 64;    // map path: candidates of the first scan beyond which the window's own V is worth its pass over the tile
     int cbw, tile_rows;  // window columns per block; tile rows resident at a time
     unsigned char *lds;  // refine_lds_bytes(n1, l, cbw, tile_rows) bytes, 16-aligned
 };
@@ -175,7 +181,6 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = NT / 64;
     const int L = g.L, hw = L >> 1, NA = g.n1 + L - 1;
     const int ti0 = g1 - g.r1 - 1 - hw, wj0 = g2 - g.r2 - 1 - hw;
-    const float thr = M - c.T;
     double *lut = reinterpret_cast<double *>(c.lds);
     double *cand_val = lut + 256;
     double *dred = cand_val + REFINE_CAP;
@@ -207,6 +212,74 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
     int tot = 0;
     for (int w = 0; w < NW; ++w) tot += ired[w];
     const int dc = dc_from_sum(tot, g.fill);
+    // The window's own V = max |pixel − dc| over its padded tile.  δ is proportional to V (header), and the flag was raised
+    // with V = 255: a window of ±2-level noise has V ≈ 3, its T is 85× smaller, and instead of thousands of pixels "within T
+    // of the maximum" (each a 4 225-term chain in the worst case: 10–26 ms per window measured) it has a handful, or the
+    // flag falls away altogether.  One pass over the tile (clamped dword loads, fill selected afterwards), ≈10 µs.
+    // Taken up front where the candidates have to be recomputed (no response map); with a map only when the first scan
+    // finds more than a few dozen candidates — on a long kernel's tile the pass costs as much as it saves otherwise (cfg5:
+    // 247 KB per window, 36 candidates).
+    float thr = M - c.T;
+    bool have_v = false;
+    auto tighten = [&]() -> bool { // true: the flag is withdrawn, the FP32 argmax stands
+        float T_eff = c.T;
+        have_v = true;
+        const int TW = g.n2 + L - 1, tq = (TW + 3) >> 2, total = NA * tq;
+        int vmax = 0;
+        if (g.fw >= 4) {
+            int a = tid / tq, q = tid - a * tq;
+            const int da = NT / tq, dq = NT - da * tq;
+            for (int e0 = tid; e0 < total; e0 += 8 * NT) {
+                uint32_t w[8];
+                int ra[8], rq[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    ra[u] = a;
+                    rq[u] = q;
+                    const bool ok = e0 + u * NT < total;
+                    const int gi = ti0 + (ok ? a : 0), gj = wj0 + 4 * (ok ? q : 0);
+                    __builtin_memcpy(&w[u], frame + (long long)min(max(gi, 0), g.fh - 1) * g.row_stride + min(max(gj, 0), g.fw - 4), 4);
+                    a += da;
+                    q += dq;
+                    if (q >= tq) { q -= tq; ++a; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (e0 + u * NT >= total) continue;
+                    const int gi = ti0 + ra[u], gj = wj0 + 4 * rq[u], gjc = min(max(gj, 0), g.fw - 4);
+                    const bool rowok = gi >= 0 && gi < g.fh;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int gjj = gj + i;
+                        if (4 * rq[u] + i >= TW) continue;
+                        const int px = (rowok && gjj >= 0 && gjj < g.fw) ? (int)((w[u] >> (8 * ((gjj - gjc) & 3))) & 0xffu) : g.fill;
+                        vmax = max(vmax, abs(px - dc));
+                    }
+                }
+            }
+        } else {
+            for (int e = tid; e < NA * TW; e += NT) {
+                const int a = e / TW, cc = e - a * TW, gi = ti0 + a, gj = wj0 + cc;
+                const int px = (gi >= 0 && gi < g.fh && gj >= 0 && gj < g.fw) ? (int)frame[(long long)gi * g.row_stride + gj] : g.fill;
+                vmax = max(vmax, abs(px - dc));
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, __shfl_xor(vmax, off, 64));
+        __syncthreads(); // (ired: everyone has read the sample sums)
+        if (lane == 0) ired[wave] = vmax;
+        __syncthreads();
+        for (int w = 0; w < NW; ++w) vmax = max(vmax, ired[w]);
+        __syncthreads();
+        if (c.T < __builtin_huge_valf()) T_eff = c.T * ((float)vmax * (1.0f / 255.0f)) * 1.00001f; // (pdog_set_exact(t, 2): T = ∞ stays)
+        thr = M - T_eff;
+        // flat tile (every pixel = dc: all responses exactly equal in both arithmetics) or a runner-up further than the
+        // window's own T below the maximum: the FP32 argmax is the reference's
+        if (c.fp32_idx >= 0 && c.T < __builtin_huge_valf() && (vmax == 0 || M - c.second > T_eff)) {
+            if (tid == 0) atomicAdd(g.ex.stat + 4, 1ull);
+            return true;
+        }
+        return false;
+    };
     // which column blocks can hold a candidate: asked in parallel, once (a serial scan of a 513-column window's 257
     // blocks cost 90 µs); blocks beyond the list's capacity are all rescanned
     const int nblk_all = (g.n2 + c.cbw - 1) / c.cbw;
@@ -219,11 +292,17 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
     __syncthreads();
     const bool blk_all = cnt[4] > REFINE_BLKCAP;
     const int nblk = blk_all ? nblk_all : cnt[4];
+    // no map, many blocks to recompute (a hard window: noise only, a faint target): the window's own V first — a window with
+    // one or two blocks listed (cfg4's one flagged window in 1 024) is recomputed sooner than its 333 KB tile is scanned
+    if (!map && nblk > 4) {
+        __syncthreads();
+        if (tighten()) return c.fp32_idx;
+    }
     // with a response map: the candidates are read straight off it — every pixel of the listed blocks with f ≥ M − T —
     // together with the column range they span
     constexpr int MAP_KPT = 4; // candidates per thread in the map path's stage 2
     bool use_map = map != nullptr && REFINE_CAP <= MAP_KPT * NT;
-    if (use_map) {
+    auto scan_map = [&]() {
         const int npx = g.n1 * g.n2, bw = c.cbw * g.n1, tot = nblk * bw;
         for (int e0 = 0; e0 < tot; e0 += 8 * NT) {
             float v[8];
@@ -248,7 +327,17 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                 }
         }
         __syncthreads();
-        if (cnt[1]) { // more candidates than the list holds (a plateau): the general path below deals with it
+    };
+    if (use_map) {
+        scan_map();
+        if (cnt[1] || cnt[0] > c.v_after) { // many pixels within the V = 255 threshold: the window's own V, then once more
+            __syncthreads();
+            if (tighten()) return c.fp32_idx;
+            if (tid == 0) { cnt[0] = 0; cnt[1] = 0; mm[0] = 0x7fffffff; mm[1] = -1; }
+            __syncthreads();
+            scan_map();
+        }
+        if (cnt[1]) { // still more candidates than the list holds (a plateau): the general path below deals with it
             __syncthreads();
             if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
             use_map = false;
@@ -591,7 +680,15 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
     pk.best = -__builtin_huge_val();
     pk.idx = 0x7fffffff;
     if (use_map) from_map(); else pk = sweep(false);
-    const bool overflow = cnt[1] != 0;
+    bool overflow = cnt[1] != 0;
+    if (overflow && !have_v) { // more candidates than the list holds under the V = 255 threshold: the window's own V, then once more
+        __syncthreads();
+        if (tighten()) return c.fp32_idx;
+        if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+        __syncthreads();
+        pk = sweep(false);
+        overflow = cnt[1] != 0;
+    }
     if (overflow) {
         __syncthreads();
         pk = sweep(true);
@@ -656,6 +753,7 @@ struct FinishGeo {
     // are single columns thin_x0 + (s − nmain)
     int slot_w, slot_last, nmain, thin_x0;
     int use_mask;                // the main slots carry per-column masks (roll kernel, slot_w = 64)
+    int v_after;                 // RefineCtx::v_after
     const float *map;            // null, or the batch's FP32 responses [n][n2][n1] (two-pass path): refine_window reads the candidates off it
     int32_t *out_ij;             // [n][2]
     int32_t *done_flag;          // NULL or host-coherent ticket word (see dog_fused.hpp): published with window 0's final answer
@@ -671,14 +769,15 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
 {
     constexpr int NT = REFINE_NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_refine[FINISH_WPB];
-    __shared__ float s_max[FINISH_WPB];
+    __shared__ int s_refine[FINISH_WPB], s_idx2[FINISH_WPB];
+    __shared__ float s_max[FINISH_WPB], s_sec2[FINISH_WPB];
     const LaunchGeo &g = fg.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {   // every wave: one window — the slots' loads go out together (one memory round trip), then a shuffle merge
         const int b = blockIdx.x * FINISH_WPB + wave;
         bool rf = false;
-        float best = 0.f;
+        float best = 0.f, sec = 0.f;
+        int bidx = -1;
         if (b < g.n) {
             Peak pk;
             peak_init(pk);
@@ -688,6 +787,8 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
                 const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
                 rf = fg.K64 && (pk.best - pk.second <= g.ex.T);
                 best = pk.best;
+                sec = pk.second;
+                bidx = pk.idx;
                 range_check(g.ex, g1, g2, g.L >> 1, g.fh, g.fw);
                 if (rf) {
                     atomicAdd(g.ex.stat, 1ull);
@@ -699,9 +800,15 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
                 }
             }
         }
-        if (lane == 0) { s_refine[wave] = rf; s_max[wave] = best; }
+        if (lane == 0) { s_refine[wave] = rf; s_max[wave] = best; s_sec2[wave] = sec; s_idx2[wave] = bidx; }
     }
     __syncthreads();
+    // windows flagged so far (up to the batches before this one), where the host can see it without a copy or a wait: it switches
+    // batches of hard windows to the response-map path (pawsome_dog.hip).  One plain store per batch — a system-scope
+    // atomic per workgroup with flagged windows cost cfg5, where every window is flagged, 0.7 ms of PCIe atomics.
+    if (blockIdx.x == 0 && tid == 0 && g.ex.range_err)
+        __hip_atomic_store(g.ex.range_err + 1, (int)__hip_atomic_load(g.ex.stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
     // the windows of this workgroup that need the refinement (rare), one after the other, all threads on each
     constexpr int SLOT_CAP = 128;
     __shared__ float s_pv[SLOT_CAP];
@@ -720,6 +827,9 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
         c.dir = fg.dir;
         c.T64 = fg.T64;
         c.T = g.ex.T;
+        c.second = s_sec2[w];
+        c.fp32_idx = s_idx2[w];
+        c.v_after = fg.v_after;
         c.cbw = fg.cbw;
         c.tile_rows = fg.tile_rows;
         c.lds = smem;

@@ -146,7 +146,8 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
     __shared__ int s_guess[2];
     __shared__ float s_sec[NW];
     __shared__ int s_refine;
-    __shared__ float s_max;
+    __shared__ float s_max, s_sec2;
+    __shared__ int s_idx2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const tap_ptr trow = as_taps(taps_row), tcol = as_taps(taps_col);
@@ -307,6 +308,8 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
                 const bool rf = fg.rp && (pk.best - pk.second <= g.ex.T);
                 s_refine = rf;
                 s_max = pk.best;
+                s_sec2 = pk.second;
+                s_idx2 = pk.idx;
                 if (rf) atomicAdd(g.ex.stat, 1ull);
                 if (!rf && publish)
                     __hip_atomic_store(fg.done_flag, fg.progress ? k + 1 : fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -327,6 +330,8 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
             c.dir = rp->dir;
             c.T64 = rp->T64;
             c.T = g.ex.T;
+            c.second = s_sec2;
+            c.fp32_idx = s_idx2;
             c.cbw = fg.ref_cbw;
             c.tile_rows = fg.ref_rows;
             c.lds = smem;

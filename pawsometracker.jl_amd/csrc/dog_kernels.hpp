@@ -75,7 +75,7 @@ __device__ __forceinline__ void peak_wave_reduce(Peak &p, int width = 64)
 // by a Float64 re-evaluation of its near-maximal pixels.
 struct ExactCtl {
     unsigned long long *stat; // [4] since the tracker was created: windows refined, column blocks rescanned, candidates, sequential chains run (diagnostics)
-    int *range_err;           // host-coherent word: set when a guess lies where the reference raises BoundsError (:45-46)
+    int *range_err;           // host-coherent words: [0] set when a guess lies where the reference raises BoundsError (:45-46) (2: a device-side wait gave up); [1] windows flagged for refinement by the finishing kernel, cumulative
     float T;                  // 2δ
 };
 // The reference's PaddedView extends radii + l past the frame (:45-46) and the filter reads radii + l÷2 around the

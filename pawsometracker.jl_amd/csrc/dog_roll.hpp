@@ -523,7 +523,8 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
     __shared__ int pi[8];
     __shared__ unsigned long long pm[8];
     __shared__ int s_refine;
-    __shared__ float s_max;
+    __shared__ float s_max, s_sec2;
+    __shared__ int s_idx2;
     const LaunchGeo &g = cg.g;
     const int tid = threadIdx.x, wave = tid >> 6, nst = blockDim.x >> 6;
     const int c_ = blockIdx.x;
@@ -553,6 +554,8 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
             cur[0] = i; cur[1] = j;
             s_refine = cg.rp && (w.best - w.second <= g.ex.T);
             s_max = w.best;
+            s_sec2 = w.second;
+            s_idx2 = w.idx;
             if (s_refine) atomicAdd(g.ex.stat, 1ull);
         }
         __syncthreads();
@@ -568,6 +571,8 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
             c.dir = rp->dir;
             c.T64 = rp->T64;
             c.T = g.ex.T;
+            c.second = s_sec2;
+            c.fp32_idx = s_idx2;
             c.cbw = cg.ref_cbw;
             c.tile_rows = cg.ref_rows;
             c.lds = smem;

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
     __shared__ float s_val[NW], s_sec[NW];
     __shared__ int s_idx[NW];
     __shared__ int s_last, s_refine;
-    __shared__ float s_max;
+    __shared__ float s_max, s_sec2;
+    __shared__ int s_idx2;
     __shared__ float s_pv[TILED_SLOT_CAP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nsub = tg.ns1 * tg.ns2;
@@ -235,6 +236,8 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
                     const bool rf = tg.rp && (w.best - w.second <= g.ex.T);
                     s_refine = rf;
                     s_max = w.best;
+                    s_sec2 = w.second;
+                    s_idx2 = w.idx;
                     s_idx[0] = i; // (the wave peaks have been consumed: the next guess travels through their slots)
                     s_idx[1] = j;
                     if (last) {
@@ -269,6 +272,8 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
                 c.dir = rp->dir;
                 c.T64 = rp->T64;
                 c.T = g.ex.T;
+                c.second = s_sec2;
+                c.fp32_idx = s_idx2;
                 c.cbw = tg.ref_cbw;
                 c.tile_rows = tg.ref_rows;
                 c.lds = smem;

@@ -62,9 +62,11 @@ struct Switches {
     bool ingest_no_nt = false, ingest_trace = false, fused_diag = false;
     bool no_exact = false;                // PDOG_NO_EXACT: trackers start with exact mode off (A/B of its cost)
     bool tiled_force = false;             // PDOG_TILED_FORCE: experiment — the tiled kernel also for windows the fused kernel serves
+    bool no_roll_map = false;             // PDOG_NO_ROLL_MAP: hard batches on the roll / ring kernels keep recomputing their candidates (A/B)
     bool no_tiled = false;                // PDOG_NO_TILED: single large windows stay on the two-pass launches (A/B of the tiled kernel)
     int tiled_sub = 0;                    // PDOG_TILED_SUB: sub-window edge of the tiled kernel (0: chosen per geometry)
     int tp_ph1 = 0, tp_php = 0;           // PDOG_TP_P=ph1,php: outputs per task of the two-pass kernels (0: per geometry)
+    int v_after = 64;                     // PDOG_V_AFTER: exact mode, map path: first-scan candidates beyond which the window's own |pixel − dc| bound is computed
     int hp_u = 8;                         // PDOG_HP_U: taps per block of the two-pass column pass (8 or 16)
     int tiled_batch = 2;                  // PDOG_TILED_BATCH: windows per batch up to which the tiled kernel is used
     bool coop = false;                    // PDOG_COOP: single-clip chains of large windows as ONE cooperative launch (dog_coop.hpp; measured slower
@@ -91,9 +93,11 @@ Switches read_switches()
     w.no_exact = on("PDOG_NO_EXACT");
     w.coop = on("PDOG_COOP");
     w.no_tiled = on("PDOG_NO_TILED");
+    w.no_roll_map = on("PDOG_NO_ROLL_MAP");
     w.tiled_force = on("PDOG_TILED_FORCE");
     if (const char *e = std::getenv("PDOG_TILED_SUB")) w.tiled_sub = std::max(0, std::min(96, std::atoi(e)));
     if (const char *e = std::getenv("PDOG_TILED_BATCH")) w.tiled_batch = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("PDOG_V_AFTER")) w.v_after = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("PDOG_HP_U")) w.hp_u = std::atoi(e) == 16 ? 16 : 8;
     if (const char *e = std::getenv("PDOG_TP_P")) {
         int a = 0, b = 0;
@@ -265,6 +269,11 @@ struct pdog_tracker {
     // two-pass path scratch
     f2 *d_V = nullptr;
     size_t v_bytes = 0;
+    // exact mode on the batch kernels of short kernels (roll / ring): windows flagged per batch as the finishing kernel reports
+    // them (h_pinned[6], cumulative); batches of HARD windows (noise only, ±1-level targets: every window flagged) switch to
+    // the response-map refinement like the two-pass path — 81–206 ms per 4096 windows of 257×257 without it
+    int flag_last = 0, flag_n_prev = 0, flag_calm = 0;
+    bool roll_map = false;
     float *d_map = nullptr; // exact mode on the two-pass path: the batch's FP32 responses, where the refinement finds its candidates
     size_t map_bytes = 0;
     int *d_dc = nullptr;
@@ -727,6 +736,7 @@ int launch_finish(pdog_tracker *t, const LaunchGeo &g, int slot_w, int slot_last
     fg.nmain = g.nslots - g.nthin;
     fg.thin_x0 = g.thin_x0;
     fg.use_mask = use_mask ? 1 : 0;
+    fg.v_after = t->sw.v_after;
     fg.out_ij = d_out_ij;
     fg.done_flag = d_done_flag;
     fg.done_value = done_value;
@@ -951,12 +961,40 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         return launch_finish(t, g, hr, 1 << 30, d_out_ij, nullptr, 0, false, t->exact ? map : nullptr);
     }
     const int grid = round_up(g.nblocks, 8);
+    // Exact mode: a batch whose predecessors flagged more than 2 % of their windows writes its responses (the kernels'
+    // RESP instances) and the finishing kernel reads the candidates off that map instead of recomputing them per window;
+    // back to the plain instances after eight batches below 0.5 %.  The count arrives through host-coherent memory, so
+    // nothing here waits for the GPU; it may lag by the batches still in flight.
+    const float *map = d_out_resp;
+    if (t->exact && !t->exact_all) {
+        const int cur = __atomic_load_n(&t->h_pinned[6], __ATOMIC_ACQUIRE), delta = cur - t->flag_last;
+        t->flag_last = cur;
+        if (t->flag_n_prev > 0) {
+            if ((long long)delta * 50 > t->flag_n_prev) { t->roll_map = true; t->flag_calm = 0; }
+            else if ((long long)delta * 200 < t->flag_n_prev) { if (++t->flag_calm >= 8) t->roll_map = false; }
+            else t->flag_calm = 0;
+        }
+        t->flag_n_prev = n;
+        const size_t need = sizeof(float) * (size_t)n * t->n1 * t->n2;
+        if (!map && t->roll_map && !t->sw.no_roll_map && need <= t->sw.map_cap) {
+            if (t->map_bytes < need) {
+                HIP_TRY(hipStreamSynchronize(t->stream));
+                if (t->d_map) (void)hipFree(t->d_map);
+                t->d_map = nullptr; t->map_bytes = 0;
+                HIP_TRY(hipMalloc(&t->d_map, need));
+                t->map_bytes = need;
+            }
+            map = t->d_map;
+            g.resp = t->d_map;
+        }
+    }
+    const bool want_resp = g.resp != nullptr;
     if (t->nthin) {
         // fork: the thin kernel only reads the frames and writes its own partial slots
         HIP_TRY(hipEventRecord(t->ev_fork, t->stream));
         HIP_TRY(hipStreamWaitEvent(t->aux_stream, t->ev_fork, 0));
         const size_t thin_lds = thin_lds_bytes(t->n1, t->L);
-        hipLaunchKernelGGL(d_out_resp ? v.thin_resp : v.thin, dim3(n * t->nthin), dim3(256), thin_lds, t->aux_stream, g,
+        hipLaunchKernelGGL(want_resp ? v.thin_resp : v.thin, dim3(n * t->nthin), dim3(256), thin_lds, t->aux_stream, g,
                            (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(t->ev_join, t->aux_stream));
@@ -965,11 +1003,11 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
 #ifdef PDOG_ABLATIONS
     if (t->sw.lds_pad) { // occupancy experiments: extra LDS per workgroup
         lds_bytes += (size_t)t->sw.lds_pad;
-        (void)raise_lds_limit((const void *)(d_out_resp ? v.fn_resp : v.fn), lds_bytes);
+        (void)raise_lds_limit((const void *)(want_resp ? v.fn_resp : v.fn), lds_bytes);
     }
 #endif
-    kernel_fn fn = d_out_resp ? v.fn_resp : v.fn;
-    if (!d_out_resp && v.roll && v.LT == 65 && v.id == 100) { // instances with statically shortened epilogue bodies for the common window heights
+    kernel_fn fn = want_resp ? v.fn_resp : v.fn;
+    if (!want_resp && v.roll && v.LT == 65 && v.id == 100) { // instances with statically shortened epilogue bodies for the common window heights
         const int cls = roll_epi_class(t->n1, 65);
 #define PDOG_EPI_PICK(C) if (cls == C) fn = (kernel_fn)dog_roll_kernel<65, false, 0, C>;
         PDOG_EPI_CLASSES(PDOG_EPI_PICK)
@@ -981,7 +1019,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     if (t->nthin) HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0)); // join before the strip combine
     // roll: 64-column strips over the first `covered` columns, the last one shifted left to stay inside; ring: tw() columns each
     const int covered = t->nthin ? t->thin_x0 : t->n2;
-    return launch_finish(t, g, v.tw(), v.roll ? std::max(0, covered - v.tw()) : (1 << 30), d_out_ij, nullptr, 0, v.roll);
+    return launch_finish(t, g, v.tw(), v.roll ? std::max(0, covered - v.tw()) : (1 << 30), d_out_ij, nullptr, 0, v.roll, t->exact ? map : nullptr);
 }
 
 } // namespace

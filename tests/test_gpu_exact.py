@@ -261,5 +261,61 @@ def test_response_map_path_equals_rescan_path(pt, monkeypatch):
     for (pa, ra, da), (pb, rb, db) in zip(with_map, without):
         assert np.array_equal(pa, pb)
         assert ra == rb and ra > 0
-        assert abs(da[2] - db[2]) <= 1e-3 * db[2]   # the same candidates (up to the rescan's own FP32 rounding at the threshold) …
-        assert da[1] <= db[1]               # … from fewer column blocks
+        # (candidate counts differ by design: without a map the window's own |pixel − dc| bound is taken before the
+        # candidates are recomputed, with a map only when the first scan finds many)
+
+
+def test_hard_batches_large_windows_exact_and_not_slow(pt, oracle, monkeypatch):
+    """257×257 windows with nothing to find (±2 noise) or a target one grey level darker under ±1 noise: every window is
+    flagged, and under the a-priori V = 255 bound thousands of pixels per window lie "within T of the maximum" (81–206 ms
+    per 4 096 windows when that went through the candidate list's overflow path).  The refinement takes the window's own
+    max |pixel − dc| (δ is proportional to it) and batches after the first read their candidates off the response map:
+    positions equal the dense oracle's, equal with and without the map, and the batch stays within 10× the raw ranking."""
+    import time
+    import torch
+    tw, ws, h, w, n, nf = 25, (257, 257), 600, 800, 256, 8
+    radii = (128, 128)
+    sig = oracle.sigma(tw)
+    K = oracle.dog_kernel(sig, True)
+    rng = np.random.Generator(np.random.PCG64(31))
+    for kind in ("noise", "faint"):
+        amp = 2 if kind == "noise" else 1
+        frames = (128 + rng.integers(-amp, amp + 1, (nf, h, w))).astype(np.uint8)
+        if kind == "faint":
+            yy, xx = np.ogrid[0:h, 0:w]
+            for k in range(nf):
+                ci, cj = int(rng.integers(200, 400)), int(rng.integers(250, 550))
+                frames[k][(yy - ci) ** 2 + (xx - cj) ** 2 <= 144] -= 1
+        fi = rng.integers(0, nf, n).astype(np.int32)
+        guesses = np.stack([rng.integers(150, 450, n), rng.integers(200, 600, n)], 1).astype(np.int32)
+        d_f, d_fi, d_g = torch.from_numpy(frames).cuda(), torch.from_numpy(fi).cuda(), torch.from_numpy(guesses).cuda()
+
+        def run(exact):
+            bt = pt.BatchTracker(h, w, tw, ws, True, 128)
+            bt.set_variant(100)                      # the roll kernel, as a large batch would run
+            bt.set_exact(exact)
+            outs = []
+            for _ in range(3):                       # the first batch recomputes its candidates, later ones use the map
+                outs.append(bt.detect(d_f, d_g, d_fi).cpu().numpy())
+            bt.sync()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                bt.detect(d_f, d_g, d_fi)
+            bt.sync()
+            dt = (time.perf_counter() - t0) / 3
+            refined = bt.exact_stats()[2]
+            bt.close()
+            assert all(np.array_equal(o, outs[0]) for o in outs)
+            return outs[0], dt, refined
+
+        got, dt, refined = run(True)
+        raw, dt_raw, _ = run(False)
+        monkeypatch.setenv("PDOG_NO_ROLL_MAP", "1")
+        got_nomap, _, _ = run(True)
+        monkeypatch.delenv("PDOG_NO_ROLL_MAP")
+        assert refined >= 5 * n                                          # every window of every batch was flagged
+        assert np.array_equal(got, got_nomap)
+        for b in range(0, n, 16):                                        # 16 windows against the reference's own arithmetic
+            assert tuple(got[b].tolist()) == oracle.detect(frames[fi[b]], 128, K, radii, tuple(guesses[b])), (kind, b)
+        print(f"{kind}: exact {dt * 1e3:.2f} ms, raw {dt_raw * 1e3:.2f} ms per {n} windows; FP32 ranking alone differs on {(got != raw).any(1).sum()}")
+        assert dt < 10 * dt_raw + 2e-3, (kind, dt, dt_raw)
