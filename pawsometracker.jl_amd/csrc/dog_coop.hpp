@@ -130,8 +130,7 @@ static __global__ __launch_bounds__(256) void dog_coop_chain_kernel(const CoopGe
                 c.cbw = cg.ref_cbw;
                 c.tile_rows = cg.ref_rows;
                 c.lds = smem;
-                const float thr = s_max - g.ex.T;
-                auto may = [&](int x0, int x1) { // partial slot s covers window columns [8s, 8s + 8)
+                auto may = [&](int x0, int x1, float thr) { // partial slot s covers window columns [8s, 8s + 8)
                     for (int s = x0 / COOP_HR; s <= (x1 - 1) / COOP_HR && s < tg.hblocks_per_win; ++s)
                         if (__hip_atomic_load(&g.part_val[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= thr) return true;
                     return false;

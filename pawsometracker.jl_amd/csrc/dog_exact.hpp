@@ -166,7 +166,7 @@ struct RefineCtx {
     unsigned char *lds;  // refine_lds_bytes(n1, l, cbw, tile_rows) bytes, 16-aligned
 };
 
-// `may(x0, x1)`: wave-uniform, false only if no pixel of window columns [x0, x1) can reach M − T.
+// `may(x0, x1, thr)`: false only if no pixel of window columns [x0, x1) can reach thr (M − T, or M − the window's own T).
 // The block's pixels go through an LDS tile of c.tile_rows rows × refine_tile_pitch bytes, staged with coalesced dword
 // loads: all NA rows at once when they fit (short kernels), otherwise slice by slice (a thread per row reading its own
 // row from memory was 10× slower: 64 cache lines per load instruction).  UNR: loads in flight per thread while staging.
@@ -283,21 +283,28 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
     // which column blocks can hold a candidate: asked in parallel, once (a serial scan of a 513-column window's 257
     // blocks cost 90 µs); blocks beyond the list's capacity are all rescanned
     const int nblk_all = (g.n2 + c.cbw - 1) / c.cbw;
-    for (int cb = tid; cb < nblk_all; cb += NT)
-        if (may(cb * c.cbw, min(g.n2, (cb + 1) * c.cbw))) {
-            const int k = atomicAdd(&cnt[4], 1);
-            if (k < REFINE_BLKCAP) blk[k] = cb * c.cbw;
-        }
-    if (tid == 0) { mm[0] = 0x7fffffff; mm[1] = -1; }
-    __syncthreads();
-    const bool blk_all = cnt[4] > REFINE_BLKCAP;
-    const int nblk = blk_all ? nblk_all : cnt[4];
-    // no map, many blocks to recompute (a hard window: noise only, a faint target): the window's own V first — a window with
-    // one or two blocks listed (cfg4's one flagged window in 1 024) is recomputed sooner than its 333 KB tile is scanned
-    if (!map && nblk > 4) {
+    auto list_blocks = [&]() {
+        for (int cb = tid; cb < nblk_all; cb += NT)
+            if (may(cb * c.cbw, min(g.n2, (cb + 1) * c.cbw), thr)) {
+                const int k = atomicAdd(&cnt[4], 1);
+                if (k < REFINE_BLKCAP) blk[k] = cb * c.cbw;
+            }
+        if (tid == 0) { mm[0] = 0x7fffffff; mm[1] = -1; }
+        __syncthreads();
+    };
+    list_blocks();
+    // no map, many blocks to recompute (a hard window: noise only, a faint target): the window's own V first, and the list
+    // again under the tighter threshold — a window with one or two blocks listed (cfg4's one flagged window in 1 024) is
+    // recomputed sooner than its 333 KB tile is scanned
+    if (!map && cnt[4] > 4) {
         __syncthreads();
         if (tighten()) return c.fp32_idx;
+        if (tid == 0) cnt[4] = 0;
+        __syncthreads();
+        list_blocks();
     }
+    const bool blk_all = cnt[4] > REFINE_BLKCAP;
+    const int nblk = blk_all ? nblk_all : cnt[4];
     // with a response map: the candidates are read straight off it — every pixel of the listed blocks with f ≥ M − T —
     // together with the column range they span
     constexpr int MAP_KPT = 4; // candidates per thread in the map path's stage 2
@@ -842,8 +849,7 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
                 s_pm[s] = fg.use_mask ? g.part_mask[(long long)b * g.nslots + s] : ~0ull;
             }
         __syncthreads();
-        const float thr = s_max[w] - g.ex.T;
-        auto may = [&](int x0, int x1) {
+        auto may = [&](int x0, int x1, float thr) {
             if (!slots_ok) return true;
             // main slots: slot s covers [min(s·slot_w, slot_last), + slot_w); only those that can intersect [x0, x1) are looked at
             const int s_lo = max(0, x0 / fg.slot_w - 1), s_hi = min(fg.nmain, x1 / fg.slot_w + 2);

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
             c.cbw = fg.ref_cbw;
             c.tile_rows = fg.ref_rows;
             c.lds = smem;
-            const int idx = refine_window<4>(NT, g, frame, g1, g2, s_max, c, [](int, int) { return true; });
+            const int idx = refine_window<4>(NT, g, frame, g1, g2, s_max, c, [](int, int, float) { return true; });
             if (tid == 0) {
                 const int x = idx / g.n1, y = idx - x * g.n1;
                 const int i = min(max(g1 - g.r1 + y, 1), g.fh);

@@ -576,8 +576,7 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
             c.cbw = cg.ref_cbw;
             c.tile_rows = cg.ref_rows;
             c.lds = smem;
-            const float thr = s_max - g.ex.T;
-            auto may = [&](int x0, int x1) { // strip s covers 64 columns from min(64 s, n2 − 64) (one partial strip when n2 < 64)
+            auto may = [&](int x0, int x1, float thr) { // strip s covers 64 columns from min(64 s, n2 − 64) (one partial strip when n2 < 64)
                 bool any = false;
                 for (int q = 0; q < nst; ++q) {
                     const int lo = g.n2 >= ROLL_TW ? min(q * ROLL_TW, g.n2 - ROLL_TW) : 0, hi = lo + ROLL_TW;

@@ -277,9 +277,8 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
                 c.cbw = tg.ref_cbw;
                 c.tile_rows = tg.ref_rows;
                 c.lds = smem;
-                const float thr = s_max - g.ex.T;
                 const bool slots_ok = nsub <= TILED_SLOT_CAP;
-                auto may = [&](int x0, int x1) { // sub-window (s1, s2) covers window columns [s2·sn2, s2·sn2 + sn2)
+                auto may = [&](int x0, int x1, float thr) { // sub-window (s1, s2) covers window columns [s2·sn2, s2·sn2 + sn2)
                     if (!slots_ok) return true;
                     for (int c2 = x0 / tg.sn2; c2 <= (x1 - 1) / tg.sn2 && c2 < tg.ns2; ++c2)
                         for (int c1 = 0; c1 < tg.ns1; ++c1)
