@@ -321,6 +321,9 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
             // sequential dense chains for genuine ties).  The tile and RT are not needed any more: their LDS is the scratch.
             // (inlined: as an out-of-line call it made EVERY launch slower — 26 → 46 µs per functor call, the kernel then
             // carries a stack; inlined, its registers spill a little into the rare path only)
+            // (An LDS copy of the window's responses for the map path of refine_window was tried as well: its stage 2 is
+            // register-hungry — 82 VGPR spills, 332 B of scratch under this kernel's 128-VGPR budget — and every launch paid:
+            // functor 26 → 35 µs, chain 10.8 → 13.0 µs per frame, hard frames no faster.)
             const refine_params_ptr rp = (refine_params_ptr)(unsigned long long)fg.rp; // read here, in the rare branch
             RefineCtx c;
             c.trow = trow;
