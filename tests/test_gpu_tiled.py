@@ -145,3 +145,52 @@ def test_ties_across_sub_window_borders_and_refinement(pt, oracle):
         want.append(gg)
     assert [tuple(r) for r in out.cpu().numpy().tolist()] == want
     bt.close()
+
+
+def test_seeded_fuzz_large_windows_vs_oracle(pt, oracle):
+    """Seeded random configurations in the tiled kernel's territory — windows 60…300 rows/columns (rectangular, odd and even),
+    target widths 10…50 (l = 29…125), frames smaller and larger than the window, bright and dark targets, guesses up to
+    l÷2 outside the frame — through the functor, a two-window batch and a three-frame chain, against the dense oracle."""
+    import torch
+    from oracle import synth
+    rng = np.random.default_rng(20261004)
+    ran = 0
+    for case in range(40):
+        fh, fw = int(rng.integers(60, 400)), int(rng.integers(60, 500))
+        tw = float(rng.choice([10, 25, 25, 33, 40, 50]))
+        ws = (int(rng.integers(60, 301)), int(rng.integers(60, 301)))
+        darker = bool(rng.integers(0, 2))
+        radii = (ws[0] // 2, ws[1] // 2)
+        l = oracle.kernel_len(oracle.sigma(tw))
+        hw = l // 2
+        if (2 * radii[0] + 1) * (2 * radii[1] + 1) * l * l > 1.2e9:      # keep the dense oracle affordable
+            continue
+        frames = rng.integers(110, 146, (3, fh, fw)).astype(np.uint8)
+        for b in range(3):
+            disc = synth.disc_frame(fh, fw, (int(rng.integers(1, fh + 1)), int(rng.integers(1, fw + 1))), max(2, int(tw)), darker)
+            mask = disc != 128
+            frames[b][mask] = disc[mask]
+        guesses = np.stack([rng.integers(-hw, fh + hw + 2, 3), rng.integers(-hw, fw + hw + 2, 3)], 1).astype(np.int32)
+        fill = oracle.mode_u8(frames[0])
+        K = oracle.dog_kernel(oracle.sigma(tw), darker)
+        tag = (case, fh, fw, tw, ws, darker)
+        bt = pt.BatchTracker(fh, fw, tw, ws, darker, fill)
+        if bt.kernel_for_batch(1) != 400:
+            bt.close()
+            continue                                                   # small enough for the fused kernel, or no sub-window fits LDS
+        ran += 1
+        exp = [oracle.detect(frames[b], fill, K, radii, tuple(guesses[b])) for b in range(3)]
+        got = bt.detect(torch.from_numpy(frames[:2]).cuda(), torch.from_numpy(guesses[:2]).cuda()).cpu().numpy()
+        assert [tuple(r) for r in got.tolist()] == exp[:2], ("batch",) + tag
+        g0 = (int(guesses[2, 0]), int(guesses[2, 1]))
+        chain = bt.detect_chain(torch.from_numpy(np.repeat(frames[2:3], 3, 0)).cuda(), g0).cpu().numpy()
+        g = g0
+        for k in range(3):
+            g = oracle.detect(frames[2], fill, K, radii, g)
+            assert tuple(int(v) for v in chain[k]) == g, ("chain", k) + tag
+        bt.close()
+        tr = pt.Tracker(frames[0], tw, ws, darker)
+        tr.img.data[...] = frames[1]
+        assert tr((int(guesses[1, 0]), int(guesses[1, 1]))) == exp[1], ("functor",) + tag
+        tr.close()
+    assert ran >= 15
