@@ -947,3 +947,50 @@ def test_epilogue_height_classes(pt, oracle, win_h):
     bt.sync()
     assert np.array_equal(got.cpu().numpy(), ref), win_h
     bt.close()
+
+
+def test_seeded_fuzz_two_pass_task_sizes_vs_oracle(pt, oracle):
+    """The two-pass kernels pick their outputs per task per geometry (row pass P = 9 / 13, column pass P = 7 / 9, 8-tap
+    blocks, register-ring windows): seeded random window shapes 20…300 on both sides — every combination of the choices —
+    kernel lengths 29…125, bright and dark targets, windows hanging over the frame; positions and a response map per
+    case against the dense oracle, batch kernels pinned to the two-pass family (large-batch form) and its small-batch form."""
+    import torch
+    from oracle import synth
+    rng = np.random.default_rng(777)
+    seen = set()
+    for case in range(60):
+        fh, fw = int(rng.integers(80, 360)), int(rng.integers(80, 420))
+        tw = float(rng.choice([10, 16, 25, 33, 40, 50]))
+        ws = (int(rng.integers(20, 301)), int(rng.integers(20, 301)))
+        darker = bool(rng.integers(0, 2))
+        radii = (ws[0] // 2, ws[1] // 2)
+        n1, n2 = 2 * radii[0] + 1, 2 * radii[1] + 1
+        l = oracle.kernel_len(oracle.sigma(tw))
+        hw = l // 2
+        if n1 * n2 * l * l > 6e8:
+            continue
+        ph1 = 13 if n2 / (-(-n2 // 208) * 208) > n2 / (-(-n2 // 144) * 144) + 0.05 else 9
+        php = 9 if n1 / (-(-n1 // 288) * 288) > n1 / (-(-n1 // 224) * 224) + 0.05 else 7
+        seen.add((ph1, php))
+        n = 20                                        # > 16 windows: the four-launch form; the first two again as a small batch
+        frames = rng.integers(118, 139, (n, fh, fw)).astype(np.uint8)
+        for b in range(n):
+            disc = synth.disc_frame(fh, fw, (int(rng.integers(1, fh + 1)), int(rng.integers(1, fw + 1))), max(2, int(tw)), darker)
+            mask = disc != 128
+            frames[b][mask] = disc[mask]
+        guesses = np.stack([rng.integers(-hw, fh + hw + 2, n), rng.integers(-hw, fw + hw + 2, n)], 1).astype(np.int32)
+        fill = oracle.mode_u8(frames[0])
+        K = oracle.dog_kernel(oracle.sigma(tw), darker)
+        exp = oracle.detect_batch_par(frames, fill, K, oracle.sigma(tw), darker, radii, guesses, separable=False)
+        bt = pt.BatchTracker(fh, fw, tw, ws, darker, fill)
+        bt.set_variant(200)
+        d_f, d_g = torch.from_numpy(frames).cuda(), torch.from_numpy(guesses).cuda()
+        got, resp = bt.detect(d_f, d_g, want_resp=True)
+        assert np.array_equal(got.cpu().numpy(), exp), ("batch", case, fh, fw, tw, ws, darker)
+        _, ref = oracle.detect(frames[0], fill, K, radii, tuple(guesses[0]), want_resp=True)
+        err, _ = _resp_err(resp[0].cpu().numpy().T, ref)
+        assert err <= 2.0 ** -24 * (6 * l + 4), ("response", case, err)   # the proven FP32 bound δ (csrc/dog_exact.hpp), not a relative one: these windows hold mostly noise
+        small = bt.detect(d_f[:2], d_g[:2]).cpu().numpy()
+        assert np.array_equal(small, exp[:2]), ("small batch", case, fh, fw, tw, ws, darker)
+        bt.close()
+    assert seen == {(9, 7), (9, 9), (13, 7), (13, 9)}, seen
