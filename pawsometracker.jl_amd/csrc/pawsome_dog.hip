@@ -39,7 +39,7 @@ namespace pdog {
     extern template __global__ void dog_chain_kernel<LT>(const ChainGeo, const f2 *, const f2 *);
 #include "roll_lengths.def"
 #undef PDOG_ROLL_L
-#define PDOG_EPI_CLASSES(X) X(10) X(2) X(16) X(14) X(6) X(4) // roll_inst.hip: window sizes 256, 512, 64, 128, 384, 1024
+#define PDOG_EPI_CLASSES(X) X(10) X(2) X(16) X(14) X(6) X(4) X(0) X(1) X(3) X(5) X(7) X(8) X(9) X(11) X(12) X(13) X(15) X(17) // roll_inst.hip: every window-height class
 #define PDOG_EPI_DECL(C) extern template __global__ void dog_roll_kernel<65, false, 0, C>(const LaunchGeo, const f2 *, const f2 *);
 PDOG_EPI_CLASSES(PDOG_EPI_DECL)
 #undef PDOG_EPI_DECL

@@ -14,9 +14,9 @@ namespace pdog {
     template __global__ void dog_chain_kernel<LT>(const ChainGeo, const f2 *, const f2 *);
 #include "roll_lengths.def"
 #undef PDOG_ROLL_L
-// l = 65 (target_width 25, the reference default) for the window-height classes of the common window sizes
-// (roll_epi_class = ((n1 + 2) ÷ 4) mod 18): statically shortened epilogue bodies.  window_size → rows → class:
-// 64 → 65 → 16, 128 → 129 → 14, 256 → 257 → 10, 384 → 385 → 6, 512 → 513 → 2, 1024 → 1025 → 4.
+// l = 65 (target_width 25, the reference default) for EVERY window-height class (roll_epi_class = ((n1 + 2) ÷ 4) mod 18):
+// statically shortened epilogue bodies, two classes per set.  window_size → rows → class, the common ones first:
+// 256 → 257 → 10, 512 → 513 → 2, 64 → 65 → 16, 128 → 129 → 14, 384 → 385 → 6, 1024 → 1025 → 4.
 #define PDOG_EPI_INST(C) template __global__ void dog_roll_kernel<65, false, 0, C>(const LaunchGeo, const f2 *, const f2 *);
 #if PDOG_ROLL_SET == 9
 PDOG_EPI_INST(10) PDOG_EPI_INST(2)
@@ -26,6 +26,24 @@ PDOG_EPI_INST(16) PDOG_EPI_INST(14)
 #endif
 #if PDOG_ROLL_SET == 11
 PDOG_EPI_INST(6) PDOG_EPI_INST(4)
+#endif
+#if PDOG_ROLL_SET == 12
+PDOG_EPI_INST(0) PDOG_EPI_INST(1)
+#endif
+#if PDOG_ROLL_SET == 13
+PDOG_EPI_INST(3) PDOG_EPI_INST(5)
+#endif
+#if PDOG_ROLL_SET == 14
+PDOG_EPI_INST(7) PDOG_EPI_INST(8)
+#endif
+#if PDOG_ROLL_SET == 15
+PDOG_EPI_INST(9) PDOG_EPI_INST(11)
+#endif
+#if PDOG_ROLL_SET == 16
+PDOG_EPI_INST(12) PDOG_EPI_INST(13)
+#endif
+#if PDOG_ROLL_SET == 17
+PDOG_EPI_INST(15) PDOG_EPI_INST(17)
 #endif
 #undef PDOG_EPI_INST
 } // namespace pdog

@@ -920,11 +920,11 @@ def test_every_roll_instance_pinned(pt, oracle, l):
         bt.close()
 
 
-@pytest.mark.parametrize("win_h", [64, 128, 256, 384, 512, 1024, 100])
+@pytest.mark.parametrize("win_h", [256, 384, 512, 1024] + [70, 74, 78, 82, 86, 90, 94, 98, 102, 106, 110, 114, 118, 122, 126, 60, 62, 66])
 def test_epilogue_height_classes(pt, oracle, win_h):
-    """dog_roll_kernel<65, false, 0, EPI>: instances with statically shortened epilogue bodies for the window-height
-    classes of the common window sizes (64 … 1024 rows; 100 = a height without an instance → the full bodies).  The
-    target sits in the LAST rows of the window, where the shortened bodies run; positions against the dense oracle."""
+    """dog_roll_kernel<65, false, 0, EPI>: instances with statically shortened epilogue bodies, one per window-height class
+    ((rows + 2) ÷ 4 mod 18): the common window sizes and one height for each of the 18 classes.  The target sits in the
+    LAST rows of the window, where the shortened bodies run; positions against the dense oracle."""
     import torch
     from oracle import synth
     tw, ws = 25, (win_h, 70)
