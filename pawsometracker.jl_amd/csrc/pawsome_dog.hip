@@ -1900,9 +1900,9 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
         int rc = ensure_capacity(t, n_clips);
         if (rc) return rc;
     }
-    if (n_clips == 1 && !t->forced_variant) { // the tiled kernel: one cooperative launch, every sub-window's workgroup resident for the clip
+    if (!t->forced_variant) { // the tiled kernel: one cooperative launch, every sub-window's workgroup of every clip resident (as many clips as that allows)
         bool launched = false;
-        if (int rc = launch_tiled(t, d_frames, frame_stride, row_stride, nullptr, d_start_guesses, 1, n_frames, d_out_ij, nullptr, t->fh, t->fw,
+        if (int rc = launch_tiled(t, d_frames, frame_stride, row_stride, nullptr, d_start_guesses, n_clips, n_frames, d_out_ij, nullptr, t->fh, t->fw,
                                   nullptr, 0, false, &launched)) return rc;
         if (launched) return PDOG_OK;
     }

@@ -194,3 +194,33 @@ def test_seeded_fuzz_large_windows_vs_oracle(pt, oracle):
         assert tr((int(guesses[1, 0]), int(guesses[1, 1]))) == exp[1], ("functor",) + tag
         tr.close()
     assert ran >= 15
+
+
+def test_few_clips_share_one_cooperative_launch(pt, oracle):
+    """pdog_detect_chains with as many clips as the device keeps resident (257×257 windows: 81 workgroups per clip, three
+    clips on 256 CUs) is ONE launch of the tiled kernel; a fourth clip falls back to the per-frame launches.  Every clip's
+    positions equal the oracle's serial chain."""
+    import torch
+    tw, ws, h, w, nf = 25, (257, 257), 420, 560, 4
+    sig = oracle.sigma(tw)
+    K = oracle.dog_kernel(sig, True)
+    radii = (128, 128)
+    for n_clips in (3, 4):
+        clips, want, starts = [], [], []
+        for c in range(n_clips):
+            frames, _ = _clip(nf, h, w, seed=100 + 10 * n_clips + c)
+            clips.append(frames)
+            g = (h // 2 + 3 * c, w // 2 - 5 * c)
+            starts.append(g)
+            chain = []
+            for k in range(nf):
+                g = oracle.detect(frames[k], FILL, K, radii, g)
+                chain.append(g)
+            want.append(chain)
+        bt = pt.BatchTracker(h, w, tw, ws, True, FILL)
+        out = bt.detect_chains(torch.from_numpy(np.stack(clips)).cuda(), torch.tensor(starts, dtype=torch.int32).cuda())
+        bt.sync()
+        got = out.cpu().numpy()
+        for c in range(n_clips):
+            assert [tuple(r) for r in got[c].tolist()] == want[c], (n_clips, c)
+        bt.close()
