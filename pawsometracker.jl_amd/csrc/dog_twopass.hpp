@@ -147,7 +147,7 @@ __device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restr
             lo[j] = ld(j);
             hi[j] = ld(L - U + j);
         }
-        auto block = [&](int sb, int k0, int nu) { // sb = (k0 / U) mod NB: a constant after unrolling; nu = taps of this block (U, or the tail's H mod U)
+        auto block = [&](int sb, int k0) { // sb = (k0 / U) mod NB: a constant after unrolling
 #pragma unroll
             for (int j = 0; j < U; ++j) { // the next block's new ends, requested before this block's arithmetic
                 lo[(sb * U + P + U - 1 + j) % R] = ld(k0 + U + (P - 1) + j);
@@ -155,27 +155,31 @@ __device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restr
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (u >= nu) break;
                 const f2 t = taps[k0 + u];
 #pragma unroll
                 for (int o = 0; o < P; ++o)
                     acc[o] = fma_bcast(lo[(sb * U + o + u) % R] + hi[(o + (U - 1) - u + R - sb * U) % R], t, acc[o]);
             }
         };
-        const int nb = H / U, rem = H - nb * U;
+        const int nb = H / U;
         int bk = 0;
         for (; bk + NB <= nb; bk += NB) {
 #pragma unroll
-            for (int sb = 0; sb < NB; ++sb) block(sb, (bk + sb) * U, U);
+            for (int sb = 0; sb < NB; ++sb) block(sb, (bk + sb) * U);
         }
-        // the whole blocks left, then the tail's H mod U pairs as one more block from the same register windows (read pair by
-        // pair from LDS they cost 2·P reads each instead of 2: at l = 109 the six tail pairs doubled the row pass's LDS reads)
 #pragma unroll
-        for (int sb = 0; sb < NB; ++sb) {
-            if (bk + sb < nb) block(sb, (bk + sb) * U, U);
-            else if (bk + sb == nb && rem) block(sb, (bk + sb) * U, rem);
+        for (int sb = 0; sb < NB - 1; ++sb)
+            if (bk + sb < nb) block(sb, (bk + sb) * U);
+        int k0 = nb * U;
+        // remaining symmetric pairs (H − k0 < U) one tap at a time, then the centre tap.  (The tail as one more, partial block
+        // from the register windows — 2 LDS reads per pair instead of 2·P — was measured: 94 → 112 VGPRs at P = 9 and the row
+        // pass 7 % SLOWER at l = 109, 8 % on cfg5.)
+        for (; k0 < H; ++k0) {
+            const f2 t = taps[k0];
+#pragma unroll
+            for (int o = 0; o < P; ++o) acc[o] = fma_bcast(ld(o + k0) + ld(o + L - 1 - k0), t, acc[o]);
         }
-        { // the centre tap
+        {
             const f2 t = taps[H];
 #pragma unroll
             for (int o = 0; o < P; ++o) acc[o] = fma_bcast(ld(o + H), t, acc[o]);
