@@ -35,6 +35,8 @@ struct FusedGeo {
     int progress;        // != 0: done_flag receives k + 1 after every frame k of clip 0 instead (a host consumer follows the chain)
     const RefineParams *rp; // exact mode's constants in device memory (dog_exact.hpp); null = off
     int ref_cbw, ref_rows; // the refinement's column-block width and resident tile rows (its scratch is this kernel's dynamic LDS)
+    int dc_host;           // ≥ 0: the window's DC level, computed by the host from the same sample grid (the functor packs the tile
+                           // itself: no sample loads, no reduction barrier); −1: sampled here
 };
 
 constexpr int FUSED_NT = 1024, FUSED_PMAX = 8, FUSED_U = 8;
@@ -194,24 +196,28 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
                     __builtin_memcpy(&v[u], colp + (long long)min(max(gi, 0), g.fh - 1) * g.row_stride, 4);
                 }
             };
-            int samp;
-            {
+            const bool host_dc = fg.dc_host >= 0 && fg.chain_len == 1;
+            int samp = 0;
+            if (!host_dc) {
                 const int si = ti0 + (int)(((long long)(tid >> 5) * NA) >> 5), sj = wj0 + (int)(((long long)(tid & 31) * fg.TWin) >> 5);
                 samp = frame[(long long)min(max(si, 0), g.fh - 1) * g.row_stride + min(max(sj, 0), g.fw - 1)];
                 if (!(si >= 0 && si < g.fh && sj >= 0 && sj < g.fw)) samp = g.fill;
             }
             uint32_t v[SU];
             load_batch(sr0, v);
+            int dc = fg.dc_host;
+            if (!host_dc) {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) samp += __shfl_xor(samp, off, 64);
-            if (lane == 0) s_sum[wave] = samp;
-            stamp(0);
-            __syncthreads();
-            stamp(4);
-            int total = 0;
+                for (int off = 32; off > 0; off >>= 1) samp += __shfl_xor(samp, off, 64);
+                if (lane == 0) s_sum[wave] = samp;
+                stamp(0);
+                __syncthreads();
+                stamp(4);
+                int total = 0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) total += s_sum[w];
-            const int dc = dc_from_sum(total, g.fill);
+                for (int w = 0; w < NW; ++w) total += s_sum[w];
+                dc = dc_from_sum(total, g.fill);
+            }
             for (int r0 = sr0; r0 < NA; r0 += srstep * SU) {
                 if (r0 != sr0) load_batch(r0, v);
 #pragma unroll

@@ -38,6 +38,7 @@ struct TiledGeo {
     int progress;
     const RefineParams *rp; // exact mode (null = off)
     int ref_cbw, ref_rows;  // refinement scratch geometry inside this kernel's LDS
+    int dc_host;            // ≥ 0: the window's DC level from the host (functor: see dog_fused.hpp); −1: sampled here
     int *cur;               // [n_clips][2]: the current guess, last arrival → everyone
     unsigned *sync;         // [n_clips][2], zero when a launch starts and when it ends: partial arrivals, frame flag (set after a refined frame only)
 };
@@ -104,22 +105,26 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
                     __builtin_memcpy(&v[u], colp + (long long)min(max(gi, 0), g.fh - 1) * g.row_stride, 4);
                 }
             };
-            int samp;
-            {
+            const bool host_dc = tg.dc_host >= 0 && tg.chain_len == 1;
+            int samp = 0;
+            if (!host_dc) {
                 const int si = wi0 + (int)(((long long)(tid >> 5) * tg.NA) >> 5), sj = wj0 + (int)(((long long)(tid & 31) * tg.TWin) >> 5);
                 samp = frame[(long long)min(max(si, 0), g.fh - 1) * g.row_stride + min(max(sj, 0), g.fw - 1)];
                 if (!(si >= 0 && si < g.fh && sj >= 0 && sj < g.fw)) samp = g.fill;
             }
             uint32_t v[SU];
             load_batch(sr0, v);
+            int dc = tg.dc_host;
+            if (!host_dc) {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) samp += __shfl_xor(samp, off, 64);
-            if (lane == 0) s_sum[wave] = samp;
-            __syncthreads();
-            int total = 0;
+                for (int off = 32; off > 0; off >>= 1) samp += __shfl_xor(samp, off, 64);
+                if (lane == 0) s_sum[wave] = samp;
+                __syncthreads();
+                int total = 0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) total += s_sum[w];
-            const int dc = dc_from_sum(total, g.fill);
+                for (int w = 0; w < NW; ++w) total += s_sum[w];
+                dc = dc_from_sum(total, g.fill);
+            }
             for (int r0 = sr0; r0 < NAs; r0 += srstep * SU) {
                 if (r0 != sr0) load_batch(r0, v);
 #pragma unroll
