@@ -274,7 +274,8 @@ struct pdog_tracker {
     // exact mode on the batch kernels of short kernels (roll / ring): windows flagged per batch as the finishing kernel reports
     // them (h_pinned[6], cumulative); batches of HARD windows (noise only, ±1-level targets: every window flagged) switch to
     // the response-map refinement like the two-pass path — 81–206 ms per 4096 windows of 257×257 without it
-    int flag_last = 0, flag_n_prev = 0, flag_calm = 0;
+    unsigned flag_last = 0;
+    int flag_n_prev = 0, flag_calm = 0;
     bool roll_map = false;
     float *d_map = nullptr; // exact mode on the two-pass path: the batch's FP32 responses, where the refinement finds its candidates
     size_t map_bytes = 0;
@@ -971,11 +972,12 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     // nothing here waits for the GPU; it may lag by the batches still in flight.
     const float *map = d_out_resp;
     if (t->exact && !t->exact_all) {
-        const int cur = __atomic_load_n(&t->h_pinned[6], __ATOMIC_ACQUIRE), delta = cur - t->flag_last;
+        const unsigned cur = (unsigned)__atomic_load_n(&t->h_pinned[6], __ATOMIC_ACQUIRE); // (the low 32 bits of a cumulative count: differences wrap correctly)
+        const long long delta = (long long)(unsigned)(cur - t->flag_last);
         t->flag_last = cur;
         if (t->flag_n_prev > 0) {
-            if ((long long)delta * 50 > t->flag_n_prev) { t->roll_map = true; t->flag_calm = 0; }
-            else if ((long long)delta * 200 < t->flag_n_prev) { if (++t->flag_calm >= 8) t->roll_map = false; }
+            if (delta * 50 > t->flag_n_prev) { t->roll_map = true; t->flag_calm = 0; }
+            else if (delta * 200 < t->flag_n_prev) { if (++t->flag_calm >= 8) t->roll_map = false; }
             else t->flag_calm = 0;
         }
         t->flag_n_prev = n;
