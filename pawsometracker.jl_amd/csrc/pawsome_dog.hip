@@ -703,6 +703,7 @@ int path_for_batch(const pdog_tracker *t, int n)
     if (v.fused) return kPathFused;
     if (t->forced_variant) return v.twopass ? kPathTwoPass : v.id;
     const bool few = v.twopass ? n <= 256 : (long long)n * (t->nstrips + (t->nthin ? 1 : 0)) < 1000;
+    if (t->sw.tiled_force && t->tiled_ok && n <= t->sw.tiled_batch) return kPathTiled; // experiment switch
     if (few && t->fused_ok) return kPathFused;
     if (t->tiled_ok && n <= t->sw.tiled_batch) return kPathTiled; // one or two windows too large for the fused kernel: one launch (dog_tiled.hpp)
     if (v.twopass || (few && t->small_twopass)) return kPathTwoPass;
