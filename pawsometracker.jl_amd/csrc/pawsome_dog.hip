@@ -68,6 +68,7 @@ struct Switches {
     int tiled_sub = 0;                    // PDOG_TILED_SUB: sub-window edge of the tiled kernel (0: chosen per geometry)
     int tp_ph1 = 0, tp_php = 0;           // PDOG_TP_P=ph1,php: outputs per task of the two-pass kernels (0: per geometry)
     int v_after = 64;                     // PDOG_V_AFTER: exact mode, map path: first-scan candidates beyond which the window's own |pixel − dc| bound is computed
+    int h1_u = 4;                         // PDOG_H1_U: taps per block of the two-pass row pass (4, or 8)
     int hp_u = 8;                         // PDOG_HP_U: taps per block of the two-pass column pass (8 or 16)
     int tiled_batch = 2;                  // PDOG_TILED_BATCH: windows per batch up to which the tiled kernel is used
     bool coop = false;                    // PDOG_COOP: single-clip chains of large windows as ONE cooperative launch (dog_coop.hpp; measured slower
@@ -100,6 +101,7 @@ Switches read_switches()
     if (const char *e = std::getenv("PDOG_TILED_SUB")) w.tiled_sub = std::max(0, std::min(96, std::atoi(e)));
     if (const char *e = std::getenv("PDOG_TILED_BATCH")) w.tiled_batch = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("PDOG_V_AFTER")) w.v_after = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("PDOG_H1_U")) w.h1_u = std::atoi(e) == 8 ? 8 : 4;
     if (const char *e = std::getenv("PDOG_HP_U")) w.hp_u = std::atoi(e) == 16 ? 16 : 8;
     if (const char *e = std::getenv("PDOG_TP_P")) {
         int a = 0, b = 0;
@@ -341,14 +343,23 @@ int twopass_pitch(int nout, int L, int rows = HP_ROWS) { return twopass_pitch_q(
 // window on P = 13 (208 per round) ran a second round 24 % full.  Measured per launch (4096 windows, same session):
 //   257 wide, l = 109:  P = 5 1.94 ms, 7 1.83, 9 1.84, 11 2.20, 13 2.39, 17 2.18   (96 VGPRs at P = 9, 155 at 13)
 //   205 wide, l = 293:  P = 5 4.35 ms, 7 4.17, 9 4.11, 11 4.61, 13 3.97            (13: one round, 98 % full)
-// ⇒ P = 9 unless P = 13 fills its rounds better.
+// ⇒ P = 9 unless P = 13 fills its rounds better.  4-tap blocks (70 / 96 VGPRs instead of 94 / 155) gave another 2–5 %:
+//   257 wide, l = 109:  P = 9 1.80 ms, 11 1.94, 13 2.17, 17 1.86;   205 wide, l = 293:  P = 9 4.20 ms, 13 3.95, 17 4.64
 // COLUMN pass (32 × P outputs per round, 8 taps per block: 76 VGPRs against 125 with 16-tap blocks, −8 % on every config):
 //   257 tall, l = 109:  P = 5 2.13 ms, 7 2.36, 9 1.96, 13 2.37
 //   205 tall, l = 293:  P = 5 3.44 ms, 7 2.50, 9 2.57, 13 3.45
 // ⇒ P = 7 unless P = 9 fills its rounds better.
 typedef void (*tp_fn)(TwoPassGeo, const f2 *);
-tp_fn h1_kernel_for(int P, bool dcin)
+tp_fn h1_kernel_for(int P, bool dcin, int U = 8)
 {
+    if (U == 4) {
+        switch (P) {
+        case 9: return dcin ? (tp_fn)dog_h1_kernel<9, 4, true> : (tp_fn)dog_h1_kernel<9, 4, false>;
+        case 17: return dcin ? (tp_fn)dog_h1_kernel<17, 4, true> : (tp_fn)dog_h1_kernel<17, 4, false>;
+        case 11: return dcin ? (tp_fn)dog_h1_kernel<11, 4, true> : (tp_fn)dog_h1_kernel<11, 4, false>;
+        default: return dcin ? (tp_fn)dog_h1_kernel<13, 4, true> : (tp_fn)dog_h1_kernel<13, 4, false>;
+        }
+    }
     switch (P) {
     case 5: return dcin ? (tp_fn)dog_h1_kernel<5, 8, true> : (tp_fn)dog_h1_kernel<5, 8, false>;
     case 7: return dcin ? (tp_fn)dog_h1_kernel<7, 8, true> : (tp_fn)dog_h1_kernel<7, 8, false>;
@@ -634,7 +645,7 @@ int choose_variant(pdog_tracker *t, int forced)
                 for (bool fin : {false, true})
                     if (int rc = raise_lds_limit((const void *)hpass8_kernel_for(t->tp_php, resp, fin, t->sw.hp_u), hl8)) return rc;
             for (bool dcin : {false, true})
-                if (int rc = raise_lds_limit((const void *)h1_kernel_for(t->tp_ph1, dcin), h1l)) return rc;
+                if (int rc = raise_lds_limit((const void *)h1_kernel_for(t->tp_ph1, dcin, t->sw.h1_u), h1l)) return rc;
             t->small_twopass = true;
         }
     }
@@ -927,7 +938,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         if (lowlat && t->exact) {
             tg.win0 = 0;
             if (ticket_armed) *ticket_armed = d_done_flag != nullptr;
-            hipLaunchKernelGGL(h1_kernel_for(t->tp_ph1, true), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
+            hipLaunchKernelGGL(h1_kernel_for(t->tp_ph1, true, t->sw.h1_u), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(hpass8_kernel_for(t->tp_php, want_resp, false, t->sw.hp_u), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             HIP_TRY(hipGetLastError());
@@ -943,7 +954,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
             tg.done_flag = d_done_flag;
             tg.done_value = done_value;
             if (ticket_armed) *ticket_armed = d_done_flag != nullptr;
-            hipLaunchKernelGGL(h1_kernel_for(t->tp_ph1, true), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
+            hipLaunchKernelGGL(h1_kernel_for(t->tp_ph1, true, t->sw.h1_u), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(hpass8_kernel_for(t->tp_php, want_resp, true, t->sw.hp_u), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             HIP_TRY(hipGetLastError());
@@ -954,7 +965,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         for (int w0 = 0; w0 < n; w0 += chunk) {
             const int nw = std::min(chunk, n - w0);
             tg.win0 = w0;
-            hipLaunchKernelGGL(h1_kernel_for(t->tp_ph1, false), dim3(nw * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
+            hipLaunchKernelGGL(h1_kernel_for(t->tp_ph1, false, t->sw.h1_u), dim3(nw * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
             HIP_TRY(hipGetLastError());
             if (hr == 8) {
                 hipLaunchKernelGGL(hpass8_kernel_for(t->tp_php, want_resp, false, t->sw.hp_u), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
