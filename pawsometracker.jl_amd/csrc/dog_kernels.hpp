@@ -52,10 +52,14 @@ __device__ __forceinline__ void peak_push(Peak &p, float v, int lin)
     p.second = __builtin_amdgcn_fmed3f(v, p.best, p.second); // second ≤ best always: the median is the new runner-up
     if (v > p.best || (v == p.best && lin < p.idx)) { p.best = v; p.idx = lin; }
 }
-// merge the peak of a disjoint set of pixels
+// Merge the peak of another set of pixels.  The sets may OVERLAP (the last strip of the roll kernel is shifted left over
+// its predecessor, dog_roll.hpp): a pixel both sets hold has the same index and — the strips being bit-identical — the
+// same value in both, and must not become its own runner-up (that flagged every window whose peak lay in the overlap for
+// a refinement that tighten() cannot withdraw: gap 0).  The true runner-up is then max(second_a, second_b).
 __device__ __forceinline__ void peak_merge(Peak &p, float ov, int oi, float os)
 {
-    p.second = fmaxf(fmaxf(p.second, os), fminf(p.best, ov));
+    const float cross = (oi == p.idx) ? -__builtin_huge_valf() : fminf(p.best, ov);
+    p.second = fmaxf(fmaxf(p.second, os), cross);
     if (ov > p.best || (ov == p.best && oi < p.idx)) { p.best = ov; p.idx = oi; }
 }
 __device__ __forceinline__ void peak_wave_reduce(Peak &p, int width = 64)

@@ -34,24 +34,28 @@
 namespace pdog {
 
 #ifndef PDOG_ROLL_LMAX
-#define PDOG_ROLL_LMAX 105
+#define PDOG_ROLL_LMAX 97
 #endif
 constexpr int ROLL_CH = 8;   // rows per sub-chunk (16 measured equal on cfg3: the kernel is VALU-bound, not latency-bound)
 constexpr int ROLL_P = 8;    // row-pass outputs per lane
 constexpr int ROLL_TW = 64;  // strip width = lanes
 constexpr int ROLL_PR = 65;  // R pitch (f2)
-constexpr int ROLL_LMIN = 17, ROLL_LMAX = PDOG_ROLL_LMAX; // kernel lengths with a roll instance (l = 4m+1).  Up to 97 the l + 7 accumulators and the
-                                              // row-pass windows fit 256 VGPRs (2 waves per SIMD); l = 101 / 105 spill 37–52 VGPRs inside the
-                                              // loop and are still faster than the two-pass path in batches (see roll_strip_call for what
-                                              // round 1's wrong rows at l = 105 led to)
+constexpr int ROLL_LMIN = 17, ROLL_LMAX = PDOG_ROLL_LMAX; // kernel lengths with a roll instance (l = 4m+1): the l + 7 accumulators, the row-pass
+                                              // windows and the loop state fit 168 VGPRs up to l = 81 (three waves per SIMD) and 256 up to l = 97
+                                              // (two); longer kernels go to dog_twopass.hpp (round 2's l = 101 / 105 instances spilled and lost to it)
+__host__ __device__ constexpr int roll_waves(int L) { return L <= 81 ? 3 : 2; } // waves per SIMD the instance is compiled for
 
 // accumulator slots: the l outputs in flight plus the sub-chunk being emitted, rounded so that the
 // slot ↔ tap mapping repeats after a whole number of sub-chunks
 __host__ __device__ constexpr int roll_slots(int L) { return (L - 1 + ROLL_CH + ROLL_CH - 1) / ROLL_CH * ROLL_CH; }
-// staging: 8 lanes per input row, each SB (multiple of 4) bytes; A pitch odd → conflict-free row-pass reads
+// staging: 8 lanes per input row, each SB (multiple of 4) bytes.  A rows are 16-byte aligned and their bases are
+// skewed by {0,1,8,9} 16-byte slots (row & 3) on a pitch that is a multiple of 256 B: the row pass reads ds_read_b128
+// quads at (row base + 8·group + 4·q) floats, and with that skew the 16 lanes of every b128 lane group
+// (MI355X_MICROARCH.md, LDS) land on 16 distinct slots of the 256-B bank row — conflict-free.
 __host__ __device__ constexpr int roll_sb(int L) { return ((ROLL_TW + L - 1 + 7) / 8 + 3) / 4 * 4; }
-__host__ __device__ constexpr int roll_pa(int L) { return (8 * roll_sb(L)) | 1; }
-__host__ __device__ constexpr size_t roll_lds_bytes(int L) { return (size_t)ROLL_CH * roll_pa(L) * 4 + (size_t)ROLL_CH * ROLL_PR * 8; }
+__host__ __device__ constexpr int roll_rs(int L) { return (8 * roll_sb(L) + 40 + 63) / 64 * 64; } // A row pitch in floats (36 of skew + the 129th column of a folded strip)
+__host__ __device__ constexpr int roll_row_base(int r, int L) { return r * roll_rs(L) + 4 * (((r & 1) ? 1 : 0) + ((r & 2) ? 8 : 0)); }
+__host__ __device__ constexpr size_t roll_lds_bytes(int L) { return (size_t)ROLL_CH * roll_rs(L) * 4 + (size_t)ROLL_CH * ROLL_PR * 8; }
 
 // Re-derive a tap pointer through an empty asm: the scalar loads that use it cannot be hoisted above
 // this point (hoisted, every block's taps are live at once and the SGPRs spill through v_writelane).
@@ -68,79 +72,88 @@ __device__ __forceinline__ tap_ptr pin_taps(tap_ptr p)
 
 // Row pass for one lane: P = 8 outputs, symmetric taps, everything in 4-cycle packed ops
 // (a lone wave issues one VALU instruction per ≈4.8 cycles whatever its width, so 2-cycle
-// scalar ops would leave the pipe half empty at 2 waves/SIMD):
-//   s2      = (a[o+k], a[o+1+k]) + (a[o+L-1-k], a[o+L-k])        v_pk_add_f32, o even
+// scalar ops would leave the pipe half empty at few waves per SIMD):
+//   s2      = (a[o+k], a[o+1+k]) + (a[o+L-1-k], a[o+L-k])                 v_pk_add_f32
 //   acc[o]  += s2.x · (g+[k], g−[k]);  acc[o+1] += s2.y · (g+[k], g−[k])   v_pk_fma_f32 (op_sel broadcast)
-// VGPR pairs must be even-aligned, so the sliding windows hold register PAIRS (a[n], a[n+1]) for
-// every n (both parities), each read from LDS as one ds_read2_b32.
-// a = &A[r][P*gx]; inputs a[0 .. P+L-2].  Taps ascending k = 0..H-1, centre last: same order for
+// VGPR pairs must be even-aligned and L − 1 is a multiple of 4, so o + k must be even: EVEN taps pair the outputs
+// (0,1) (2,3) (4,5) (6,7), ODD taps pair (−1,0) (1,2) (3,4) (5,6) (7,8) — a fifth v_pk_add_f32 whose outer halves
+// are not used, instead of the ≈50 v_pk_mov_b32 / v_mov_b32 per sub-chunk that assembled odd-aligned register pairs
+// in round 2.  Every operand is then an even pair E[p] = (a[2p], a[2p+1]) of the lane's 16-byte aligned span: the
+// inputs arrive as ds_read_b128 quads, each read once, and the sliding windows shrink to 3 + 3 quads (24 VGPRs
+// instead of 40 + 16 staged) — what lets the kernel run three waves per SIMD.
+//   tap k = 4J+u, block J:  lo pairs E[2J … 2J+5] = quads J … J+2,  hi pairs E[H−2J−2 … H−2J+3] = quads H/2−J−1 … H/2−J+1
+// a = &A[r][P*gx] (16-byte aligned); inputs a[0 .. P+L-2].  Taps ascending k = 0..H-1, centre last: same order for
 // every output, so equal inputs give bit-equal outputs.
+typedef float f4 __attribute__((ext_vector_type(4)));
 template <int L>
 __device__ __forceinline__ void roll_row_pass(f2 (&acc)[ROLL_P], const float *a, tap_ptr taps)
 {
-    constexpr int P = ROLL_P, H = L / 2, U = 4, NP = P / 2;
-    constexpr int W = 2 * (NP - 1) + U; // pairs per window: n = base + (2*op + u)
-    // (Loading the pairs at odd n through a second, laundered pointer — so that the compiler reloads them instead of
-    // assembling them with ≈50 v_pk_mov_b32 / v_mov_b32 per sub-chunk — was measured 40 % SLOWER: the row pass is as
-    // close to the LDS pipe's limit as to the VALU's.)
-    auto pair_at = [&](int n) { return f2{a[n], a[n + 1]}; };
-    f2 lo[W], hi[W];
+    constexpr int P = ROLL_P, H = L / 2, U = 4, NB = (H + U - 1) / U, HQ = H / 2;
+    static_assert(P == 8 && H % 2 == 0, "the pairing below is written for 8 outputs and L = 4m + 1");
+    auto quad = [&](int q) { return *reinterpret_cast<const f4 *>(a + 4 * q); };
+    auto half = [](const f4 &v, int h) { return h ? __builtin_shufflevector(v, v, 2, 3) : __builtin_shufflevector(v, v, 0, 1); };
+    f4 lw[3], hw[3]; // quads J … J+2 and HQ−J−1 … HQ−J+1
 #pragma unroll
-    for (int j = 0; j < W; ++j) {
-        lo[j] = pair_at(j);
-        hi[j] = pair_at(L - U + j); // base of the first hi window: (L-1) - (U-1)
+    for (int j = 0; j < 3; ++j) {
+        lw[j] = quad(j);
+        hw[j] = quad(HQ - 1 + j);
     }
     f2 tn[U];
     tap_ptr tb = pin_taps(taps); // ONE base re-pinned in place per block: the loads below keep constant offsets from it
 #pragma unroll                   // (an opaque pointer per block made 9 loop-invariant address pairs, all spilled to VGPR lanes)
     for (int j = 0; j < U; ++j) tn[j] = tb[j];
 #pragma unroll
-    for (int k0 = 0; k0 < H; k0 += U) {
-        const int nu = (H - k0 < U) ? (H - k0) : U; // the last block is partial when H is not a multiple of U
-        const bool more = (k0 + U < H);
+    for (int J = 0; J < NB; ++J) {
+        const int k0 = U * J;
+        const int nu = (H - k0 < U) ? (H - k0) : U; // the last block holds two taps when H is not a multiple of 4
+        const bool more = (J + 1 < NB);
         f2 t[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) t[j] = tn[j];
-        f2 nlo[U], nhi[U];
+        f4 nl = lw[2], nh = hw[0];
         tb = pin_taps(tb);
         const tap_ptr tnext = tb + (more ? k0 + U : H);
         if (more) {
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                tn[j] = tnext[j]; // may run past tap H−1 on the last full load: those entries are never used
-                nlo[j] = pair_at(k0 + U + (W - U) + j); // new upper end of the next lo window
-                nhi[j] = pair_at(L - U - (k0 + U) + j); // new lower end of the next hi window
-            }
+            for (int j = 0; j < U; ++j) tn[j] = tnext[j]; // may run past tap H−1 on the last full load: those entries are never used
+            nl = quad(J + 3);      // new upper quad of the next lo window
+            nh = quad(HQ - J - 2); // new lower quad of the next hi window
         } else {
             tn[0] = tnext[0]; // centre tap
-#pragma unroll
-            for (int j = 0; j < NP; ++j) nlo[j] = pair_at(H + 2 * j); // (a[o+H], a[o+1+H]), o = 2j
         }
+        auto LO = [&](int p) { return half(lw[(p >> 1) - J], p & 1); };
+        auto HI = [&](int p) { return half(hw[(p >> 1) - (HQ - J - 1)], p & 1); };
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (u < nu) {
+                const int k = k0 + u;
+                if ((k & 1) == 0) {
 #pragma unroll
-                for (int op = 0; op < NP; ++op) {
-                    const f2 s2 = lo[2 * op + u] + hi[2 * op + (U - 1) - u];
-                    acc[2 * op] = fma_bcast(s2.x, t[u], acc[2 * op]);
-                    acc[2 * op + 1] = fma_bcast(s2.y, t[u], acc[2 * op + 1]);
+                    for (int m = 0; m < 4; ++m) {
+                        const f2 s2 = LO(k / 2 + m) + HI(H - k / 2 + m);
+                        acc[2 * m] = fma_bcast(s2.x, t[u], acc[2 * m]);
+                        acc[2 * m + 1] = fma_bcast(s2.y, t[u], acc[2 * m + 1]);
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 5; ++m) {
+                        const f2 s2 = LO((k - 1) / 2 + m) + HI(H - (k + 1) / 2 + m);
+                        if (m >= 1) acc[2 * m - 1] = fma_bcast(s2.x, t[u], acc[2 * m - 1]);
+                        if (m <= 3) acc[2 * m] = fma_bcast(s2.y, t[u], acc[2 * m]);
+                    }
                 }
             }
         }
         if (more) {
-#pragma unroll
-            for (int j = 0; j < W - U; ++j) lo[j] = lo[j + U];
-#pragma unroll
-            for (int j = 0; j < U; ++j) lo[W - U + j] = nlo[j];
-#pragma unroll
-            for (int j = W - 1; j >= U; --j) hi[j] = hi[j - U];
-#pragma unroll
-            for (int j = 0; j < U; ++j) hi[j] = nhi[j];
+            lw[0] = lw[1]; lw[1] = lw[2]; lw[2] = nl;
+            hw[2] = hw[1]; hw[1] = hw[0]; hw[0] = nh;
         } else {
+            // centre tap: a[o + H], the pairs E[HQ … HQ+3] — inside the last lo window whatever H mod 4 is
 #pragma unroll
-            for (int op = 0; op < NP; ++op) {
-                acc[2 * op] = fma_bcast(nlo[op].x, tn[0], acc[2 * op]);
-                acc[2 * op + 1] = fma_bcast(nlo[op].y, tn[0], acc[2 * op + 1]);
+            for (int m = 0; m < 4; ++m) {
+                const f2 c2 = LO(HQ + m);
+                acc[2 * m] = fma_bcast(c2.x, tn[0], acc[2 * m]);
+                acc[2 * m + 1] = fma_bcast(c2.y, tn[0], acc[2 * m + 1]);
             }
         }
 #pragma unroll
@@ -249,11 +262,11 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
     static_assert(CH == 8 && L % 4 == 1 && L >= ROLL_LMIN && L <= ROLL_LMAX, "roll kernel instance out of range");
     constexpr int SB = roll_sb(L);     // staged bytes per lane per sub-chunk (16 for l = 65)
     constexpr int SEGS = 64 / CH;      // lanes per row
-    constexpr int PA = roll_pa(L);
+    constexpr int RS = roll_rs(L);     // A row pitch in floats
     constexpr int RPASS = CH / 8;      // row-pass rounds: 8 rows × 8 groups of P = 8 outputs per round
 
     float *A = reinterpret_cast<float *>(smem);
-    f2 *Rb = reinterpret_cast<f2 *>(smem + CH * PA * 4);
+    f2 *Rb = reinterpret_cast<f2 *>(smem + CH * RS * 4);
 
     const int lane = threadIdx.x & 63;
     // strips are 64 wide; the last one is shifted left to stay inside the window (overlap
@@ -322,15 +335,14 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
     for (int sc = 0; sc < nsub; ++sc) {
         // ---- stage this sub-chunk from the prefetched registers, request the next ----
         if (!(ABL & 4)) {
-            float *dst = A + srow * PA + SB * sseg;
+            float *dst = A + roll_row_base(srow, L) + SB * sseg; // 16-byte aligned: ds_write_b128
             const f2 ndc = f2{-(float)dc, -(float)dc};
 #pragma unroll
-            for (int i = 0; i < SB; i += 2) { // two pixels per v_pk_add_f32 (v_cvt_f32_ubyteN each): exact integers either way
-                const uint32_t word = pre[i >> 2];
-                f2 v = f2{(float)((word >> (8 * (i & 3))) & 0xffu), (float)((word >> (8 * ((i + 1) & 3))) & 0xffu)};
-                v = v + ndc;
-                dst[i] = v.x;
-                dst[i + 1] = v.y;
+            for (int q = 0; q < SB / 4; ++q) { // two pixels per v_pk_add_f32 (v_cvt_f32_ubyteN each): exact integers either way
+                const uint32_t word = pre[q];
+                const f2 v01 = f2{(float)(word & 0xffu), (float)((word >> 8) & 0xffu)} + ndc;
+                const f2 v23 = f2{(float)((word >> 16) & 0xffu), (float)(word >> 24)} + ndc;
+                *reinterpret_cast<f4 *>(dst + 4 * q) = f4{v01.x, v01.y, v23.x, v23.y};
             }
             if (!(ABL & 8)) load16((sc + 1) * CH + srow, pre);
         }
@@ -344,7 +356,7 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
                 f2 racc[P];
 #pragma unroll
                 for (int o = 0; o < P; ++o) racc[o] = f2{0.f, 0.f};
-                roll_row_pass<L>(racc, A + (rr + 8 * h) * PA + rgx * P, trow);
+                roll_row_pass<L>(racc, A + roll_row_base(rr + 8 * h, L) + rgx * P, trow);
                 f2 *dst = Rb + (rr + 8 * h) * ROLL_PR + rgx * P;
 #pragma unroll
                 for (int o = 0; o < P; ++o) dst[o] = racc[o];
@@ -446,8 +458,7 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
 // The strip as an out-of-line function with a register allocation of its own.  The persistent chain kernel calls it
 // (inlined into that kernel's frame loop the accumulators, the row-pass windows and the loop state did not fit:
 // 18–64 VGPRs went to scratch inside the hot loop, and the l = 105 instance returned wrong rows in round 1 while
-// the batch kernel of the same length, compiled separately, was correct); so do the batch kernels of the longest
-// instances, so that batch and chain run the SAME machine code there.  Arguments arrive in VGPRs by the calling
+// the batch kernel of the same length, compiled separately, was correct).  Arguments arrive in VGPRs by the calling
 // convention: everything uniform goes back to SGPRs with readfirstlane (tap tables are read with scalar loads).
 __device__ __forceinline__ unsigned long long uniform_u64(const void *p)
 {
@@ -469,10 +480,9 @@ __device__ __attribute__((noinline)) void roll_strip_call(const LaunchGeo *gp, c
     *out = pk;
     *mask = m;
 }
-constexpr int ROLL_CALL_LMIN = 101; // batch kernels from this length on run the out-of-line strip too
 
 template <int LT, bool RESP, int ABL = 0, int EPI = -1>
-__global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, const f2 *__restrict__ taps_row,
+__global__ __launch_bounds__(64, roll_waves(LT)) void dog_roll_kernel(const LaunchGeo g, const f2 *__restrict__ taps_row,
                                                          const f2 *__restrict__ taps_col)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -487,10 +497,7 @@ __global__ __launch_bounds__(64, 2) void dog_roll_kernel(const LaunchGeo g, cons
     const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
     Peak pk;
     unsigned long long mask;
-    if constexpr (LT >= ROLL_CALL_LMIN && !RESP && ABL == 0)
-        roll_strip_call<LT>(&g, taps_row, taps_col, smem, frame, g1, g2, s, b, &pk, &mask);
-    else
-        roll_strip<LT, RESP, ABL, EPI>(g, taps_row, taps_col, smem, frame, g1, g2, s, b, logical, pk, mask);
+    roll_strip<LT, RESP, ABL, EPI>(g, taps_row, taps_col, smem, frame, g1, g2, s, b, logical, pk, mask);
     if (threadIdx.x == 0) {
         g.part_mask[b * g.nslots + s] = mask;
         g.part_val[b * g.nslots + s] = pk.best;

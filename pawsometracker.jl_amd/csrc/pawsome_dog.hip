@@ -574,10 +574,10 @@ int launch_tiled(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     return PDOG_OK;
 }
 
-// Longest kernel the roll instances serve by default.  The l = 101 / 105 instances spill in their loop and measured 3.95 /
-// 4.15 ms per 4096 windows of 257×257 against 3.54 / 3.65 ms for the two-pass kernels (since those run register-ring
-// windows and per-geometry task sizes); they stay selectable (variants 201, 205) and serve the persistent multi-clip chain.
-constexpr int kRollBatchLmax = 97;
+// Longest kernel with a roll instance (dog_roll.hpp, roll_lengths.def).  Round 2 also built l = 101 / 105: they spilled in
+// their loop and measured 3.95 / 4.15 ms per 4096 windows of 257×257 against 3.54 / 3.65 ms for the two-pass kernels, so
+// they are gone; longer kernels take the two-pass path.
+constexpr int kRollBatchLmax = ROLL_LMAX;
 
 int choose_variant(pdog_tracker *t, int forced)
 {

@@ -319,3 +319,78 @@ def test_hard_batches_large_windows_exact_and_not_slow(pt, oracle, monkeypatch):
             assert tuple(got[b].tolist()) == oracle.detect(frames[fi[b]], 128, K, radii, tuple(guesses[b])), (kind, b)
         print(f"{kind}: exact {dt * 1e3:.2f} ms, raw {dt_raw * 1e3:.2f} ms per {n} windows; FP32 ranking alone differs on {(got != raw).any(1).sum()}")
         assert dt < 10 * dt_raw + 2e-3, (kind, dt, dt_raw)
+
+
+@pytest.mark.parametrize("win_w", [100, 201, 481])
+def test_peak_in_strip_overlap_is_not_its_own_runner_up(pt, oracle, win_w):
+    """The roll kernel's last strip is shifted left over its predecessor; a peak inside the overlap reaches the strip
+    combine twice (same index, same value).  Round 2 merged it with itself: runner-up = best, gap 0 ≤ T, so every
+    well-tracked target of such a window (the centre column of window_size = 100 lies in the overlap) was refined
+    although nothing was near a tie.  Clean discs (no noise: answer = disc centre by symmetry, SURVEY §8c i) with the
+    target inside the overlap, widths 100 / 201 / 481, batch kernel (variant 100) and the persistent chain kernel:
+    oracle positions, NO window refined, and exact mode on costs what exact mode off costs."""
+    import torch
+    tw, win_h = 25, 33
+    ws = pt.fix_window_size((win_w, win_h))          # (w, h) → (h, w) like the reference (:70)
+    radii = (ws[0] // 2, ws[1] // 2)
+    n2 = 2 * radii[1] + 1
+    assert n2 % 64 > 6, "widths whose remainder goes to a last, shifted strip"
+    lo, hi = n2 - 64, (n2 // 64) * 64 - 1            # window columns the last two strips share
+    n, fh, fw = 1024, 72, n2 + 80
+    rng = np.random.Generator(np.random.PCG64(win_w))
+    frames = np.full((n, fh, fw), 128, np.uint8)
+    guesses = np.empty((n, 2), np.int32)
+    centres = np.empty((n, 2), np.int32)
+    yy, xx = np.mgrid[0:fh, 0:fw]
+    for b in range(n):
+        gi, gj = fh // 2 + int(rng.integers(-3, 4)), fw // 2 + int(rng.integers(-8, 9))   # 1-based guess
+        x = int(rng.integers(lo + 2, hi - 1))                                             # window column of the disc centre, inside the overlap
+        ci, cj = gi + int(rng.integers(-3, 4)), gj - radii[1] + x                          # 1-based frame position
+        frames[b][(yy - (ci - 1)) ** 2 + (xx - (cj - 1)) ** 2 <= (tw // 2) ** 2] = 0
+        guesses[b] = (gi, gj)
+        centres[b] = (ci, cj)
+    fill = 128
+    K = oracle.dog_kernel(oracle.sigma(tw), True)
+    sep = oracle.detect_batch_par(frames[:64], fill, K, oracle.sigma(tw), True, radii, guesses[:64], separable=True)
+    assert np.array_equal(sep, centres[:64])
+    d_frames, d_guesses = torch.from_numpy(frames).cuda(), torch.from_numpy(guesses).cuda()
+    bt = pt.BatchTracker(fh, fw, tw, ws, True, fill)
+    bt.set_variant(100)
+    assert bt.kernel_for_batch(n) == 100
+
+    def timed(reps=7):
+        best = 1e9
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            bt.use_torch_stream()
+            e0.record()
+            for _ in range(4):
+                out = bt.detect(d_frames, d_guesses)
+            e1.record()
+            bt.sync()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 4)
+        return out.cpu().numpy(), best
+
+    got, t_on = timed()
+    assert np.array_equal(got, centres), win_w
+    assert bt.exact_stats()[2] == 0, (win_w, bt.exact_stats())
+    bt.set_exact(False)
+    raw, t_off = timed()
+    bt.set_exact(True)
+    assert np.array_equal(raw, centres)
+    print(f"width {win_w}: exact on {t_on:.4f} ms, off {t_off:.4f} ms per {n} windows")
+    assert t_on <= 1.05 * t_off + 0.002
+    # persistent chain kernel: 256 clips x 4 frames of the same windows, each frame searched around the previous answer
+    clips = d_frames.view(256, 4, fh, fw)
+    starts = d_guesses.view(256, 4, 2)[:, 0, :].contiguous()
+    out = bt.detect_chains(clips, starts).cpu().numpy()
+    bt.sync()
+    assert bt.exact_stats()[2] == 0, (win_w, "chain", bt.exact_stats())
+    for c in range(0, 256, 17):
+        g = tuple(int(v) for v in guesses[4 * c])
+        for k in range(4):
+            ref = oracle.detect_batch_par(frames[4 * c + k][None], fill, K, oracle.sigma(tw), True, radii, np.array([g], np.int32), separable=True)[0]
+            assert tuple(int(v) for v in out[c][k]) == tuple(int(v) for v in ref), (win_w, c, k)
+            g = tuple(int(v) for v in ref)
+    bt.close()
