@@ -771,6 +771,7 @@ constexpr int REFINE_NT = 256;
 
 constexpr int FINISH_WPB = REFINE_NT / 64; // windows per workgroup: a wave combines one window's partials
 
+#ifndef PDOG_ROLL_INST_ONLY // the roll instantiation units (roll_inst.hip) do not need a private copy of this kernel each
 static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const FinishGeo fg, const f2 *__restrict__ taps_row,
                                                                       const f2 *__restrict__ taps_col)
 {
@@ -880,5 +881,7 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
         __syncthreads();
     }
 }
+
+#endif // PDOG_ROLL_INST_ONLY
 
 } // namespace pdog

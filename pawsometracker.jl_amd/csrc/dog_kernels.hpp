@@ -458,6 +458,7 @@ __global__ __launch_bounds__(NT, 2) void dog_window_kernel(const LaunchGeo g, co
     }
 }
 
+#ifndef PDOG_ROLL_INST_ONLY
 // mode(_img), src/PawsomeTracker.jl:47, for a frame that already lives on the device.  StatsBase.mode keeps
 // the value whose count FIRST exceeds the running maximum while scanning the h×w view column-major.  Every
 // value that ends with the maximum count M reaches M at its LAST occurrence, so the winner is: largest count,
@@ -483,5 +484,7 @@ static __global__ __launch_bounds__(256) void dog_mode_kernel(const uint8_t *__r
         atomicMax(&last[threadIdx.x], slast[threadIdx.x]);
     }
 }
+
+#endif // PDOG_ROLL_INST_ONLY
 
 } // namespace pdog

@@ -34,7 +34,7 @@
 namespace pdog {
 
 #ifndef PDOG_ROLL_LMAX
-#define PDOG_ROLL_LMAX 97
+#define PDOG_ROLL_LMAX 149
 #endif
 constexpr int ROLL_CH = 8;   // rows per sub-chunk (16 measured equal on cfg3: the kernel is VALU-bound, not latency-bound)
 constexpr int ROLL_P = 8;    // row-pass outputs per lane
@@ -395,7 +395,7 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
             }
             // (no reset: the emitted slots are reused S rows later, and their first term is a multiply, see roll_col_body)
         };
-        static_assert(NBODY <= 16 && NPRO < NBODY && NPRO <= 16, "extend the phase switches");
+        static_assert(NBODY <= 20 && NPRO < NBODY && NPRO <= 20, "extend the phase switches");
 #define PDOG_FULL(k) case k: emit(std::integral_constant<int, (k) % NBODY>{}, std::integral_constant<int, roll_col_blocks(L)>{}, std::integral_constant<int, 0>{}); break;
 #define PDOG_PRO(k)                                                                                                   \
     case k:                                                                                                           \
@@ -422,13 +422,15 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
             switch (sc) {
                 PDOG_PRO(0) PDOG_PRO(1) PDOG_PRO(2) PDOG_PRO(3) PDOG_PRO(4) PDOG_PRO(5) PDOG_PRO(6) PDOG_PRO(7)
                 PDOG_PRO(8) PDOG_PRO(9) PDOG_PRO(10) PDOG_PRO(11) PDOG_PRO(12) PDOG_PRO(13) PDOG_PRO(14) PDOG_PRO(15)
+                PDOG_PRO(16) PDOG_PRO(17) PDOG_PRO(18) PDOG_PRO(19)
             default: break;
             }
         } else {
             switch (phase) {
                 PDOG_FULL(0) PDOG_FULL(1) PDOG_FULL(2) PDOG_FULL(3) PDOG_FULL(4) PDOG_FULL(5) PDOG_FULL(6) PDOG_FULL(7)
-                PDOG_FULL(8) PDOG_FULL(9) PDOG_FULL(10) PDOG_FULL(11) PDOG_FULL(12) PDOG_FULL(13) PDOG_FULL(14)
-            default: emit(std::integral_constant<int, 15 % NBODY>{}, std::integral_constant<int, roll_col_blocks(L)>{}, std::integral_constant<int, 0>{}); break;
+                PDOG_FULL(8) PDOG_FULL(9) PDOG_FULL(10) PDOG_FULL(11) PDOG_FULL(12) PDOG_FULL(13) PDOG_FULL(14) PDOG_FULL(15)
+                PDOG_FULL(16) PDOG_FULL(17) PDOG_FULL(18)
+            default: emit(std::integral_constant<int, 19 % NBODY>{}, std::integral_constant<int, roll_col_blocks(L)>{}, std::integral_constant<int, 0>{}); break;
             }
         }
 #undef PDOG_FULL
@@ -605,6 +607,7 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
     }
 }
 
+#ifndef PDOG_ROLL_INST_ONLY
 // Step of a multi-clip chain run as ordinary batches: file the step's answers under [clip][frame] and make
 // them the next step's guesses.
 static __global__ void dog_chain_step_kernel(const int *__restrict__ step_ij, int *__restrict__ cur, int *__restrict__ out_ij,
@@ -618,6 +621,8 @@ static __global__ void dog_chain_step_kernel(const int *__restrict__ step_ij, in
     cur[2 * c] = i;
     cur[2 * c + 1] = j;
 }
+
+#endif // PDOG_ROLL_INST_ONLY
 
 // dynamic LDS of dog_thin_kernel: the R column (f2 per input row) and the column's input patch as bytes
 __host__ __device__ constexpr size_t thin_lds_bytes(int n1, int L) { return ((size_t)(n1 + L - 1) * sizeof(f2) + 15) / 16 * 16 + (size_t)(n1 + L - 1) * ((L + 3) / 4 * 4); }

@@ -236,6 +236,13 @@ constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr size_t kMaxLds = 160 * 1024;
 constexpr int kThinMax = 6; // remainder columns done by dog_thin_kernel instead of one more strip
 
+bool has_roll_instance(int L)
+{
+    for (int i = 0; i < kNumVariants; ++i)
+        if (kVariants[i].roll && kVariants[i].LT == L && kVariants[i].id >= 100 && kVariants[i].id < 300) return true;
+    return false;
+}
+
 const Variant *find_variant(int id)
 {
     for (int i = 0; i < kNumVariants; ++i)
@@ -577,7 +584,6 @@ int launch_tiled(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
 // Longest kernel with a roll instance (dog_roll.hpp, roll_lengths.def).  Round 2 also built l = 101 / 105: they spilled in
 // their loop and measured 3.95 / 4.15 ms per 4096 windows of 257×257 against 3.54 / 3.65 ms for the two-pass kernels, so
 // they are gone; longer kernels take the two-pass path.
-constexpr int kRollBatchLmax = ROLL_LMAX;
 
 int choose_variant(pdog_tracker *t, int forced)
 {
@@ -592,11 +598,12 @@ int choose_variant(pdog_tracker *t, int forced)
         }
         if (v.LT != 0 && v.LT != t->L) continue;
         if (v.lds(t->L) > kMaxLds) continue;
-        if (forced < 0 && t->L > kRollBatchLmax && !v.twopass) continue; // long kernels: two-pass path (measured 1.7× the ring kernel at l = 293)
+        const bool roll_serves = has_roll_instance(t->L);
+        if (forced < 0 && t->L >= ROLL_LMIN && !roll_serves && !v.twopass) continue; // long kernels without a roll instance: two-pass path (measured 1.7× the ring kernel at l = 293)
         if (v.twopass) {
             const size_t hl = (size_t)HP_ROWS * twopass_pitch(t->n1, t->L) * sizeof(f2);
             if (hl > kMaxLds - 1024) continue;
-            if (forced < 0 && t->L <= kRollBatchLmax) continue; // the ring/roll kernels win where a spill-free roll instance exists
+            if (forced < 0 && (roll_serves || t->L < ROLL_LMIN)) continue; // the ring/roll kernels win where a spill-free roll instance exists
             if (!best || forced >= 0) { best = &v; best_cost = 0.0; }
             continue;
         }

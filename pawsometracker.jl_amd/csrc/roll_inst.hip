@@ -1,6 +1,7 @@
 // roll_inst.hip — explicit instantiations of the rolling-accumulator kernels (dog_roll.hpp) for the kernel
 // lengths of one PDOG_ROLL_SET (roll_lengths.def).  Compiled once per set so that the sets build in parallel;
 // pawsome_dog.hip declares the same instantiations `extern` and only takes their addresses.
+#define PDOG_ROLL_INST_ONLY // no private copies of the static kernels (finish, mode, chain step): pawsome_dog.hip holds them
 #include "dog_roll.hpp"
 #ifndef PDOG_ROLL_SET
 #error "compile with -DPDOG_ROLL_SET=<n>"

@@ -868,15 +868,15 @@ def test_power_of_two_contrast_scales_the_response_exactly(pt):
 
 
 def _tw_for_kernel_len(oracle, l):
-    for tw10 in range(20, 600):
+    for tw10 in range(20, 700):
         if oracle.kernel_len(oracle.sigma(tw10 / 10)) == l:
             return tw10 / 10
     raise AssertionError(l)
 
 
-@pytest.mark.parametrize("l", list(range(17, 98, 4)))
+@pytest.mark.parametrize("l", list(range(17, 150, 4)))
 def test_every_roll_instance_pinned(pt, oracle, l):
-    """One compiled roll-kernel instance per kernel length l = 17, 21, … 97 (dog_roll.hpp).  Small batches are
+    """One compiled roll-kernel instance per kernel length l = 17, 21, … 149 (dog_roll.hpp).  Small batches are
     switched to the fused / two-pass kernels at launch, so the instance is pinned here (pdog_set_variant) and run on
     window shapes that cover a partial strip, an overlapping last strip and remainder columns for the thin kernel —
     positions and the dense response against the oracle, plus the persistent chain kernel of the same instance."""
@@ -893,7 +893,7 @@ def test_every_roll_instance_pinned(pt, oracle, l):
         fill = oracle.mode_u8(frames[0])
         bt = pt.BatchTracker(h, w, tw, ws, True, fill)
         vid = 100 if l == 65 else 100 + l
-        assert bt.info().variant == vid and bt.info().kernel_len == l   # the roll instance is the tracker's batch kernel up to l = 97
+        assert bt.info().variant == vid and bt.info().kernel_len == l   # the roll instance is the tracker's batch kernel up to l = 149
         bt.set_variant(vid)
         assert bt.kernel_for_batch(n) == vid
         got, resp = bt.detect(torch.from_numpy(frames).cuda(), torch.from_numpy(guesses).cuda(), want_resp=True)
