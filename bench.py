@@ -70,20 +70,22 @@ def make_frames(torch, n, h, w, tw, radii, seed, noise, device):
 
 def stored_traffic(workload, variant, batch):
     """HBM bytes per STEP (every kernel a step launches, summed) from the committed PMC passes
-    (profiles/traffic_r02.json, written by tools/traffic_from_pmc.py from separate FETCH_SIZE / WRITE_SIZE runs);
+    (profiles/traffic_r03.json, else traffic_r02.json; written by tools/traffic_from_pmc.py from separate FETCH_SIZE / WRITE_SIZE runs);
     None when no counter run exists for this workload/variant/batch (counters cannot be read from inside a timed
     run: rocprofv3 wraps the process)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic_r02.json")) as f:
-            rec = json.load(f).get(workload)
-        if not rec or rec["variant"] != variant or rec["batch"] != batch:
-            return None
-        total = 0.0
-        for k in rec["kernels"].values():
-            total += (k["fetch_size_kib"] * k["fetch_correction"] + k["write_size_kib"]) * k["launches_per_step"]
-        return int(total * 1024)
-    except (OSError, KeyError, ValueError, TypeError):
-        return None
+    for name in ("traffic_r03.json", "traffic_r02.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rec = json.load(f).get(workload)
+            if not rec or rec["variant"] != variant or rec["batch"] != batch:
+                continue
+            total = 0.0
+            for k in rec["kernels"].values():
+                total += (k["fetch_size_kib"] * k["fetch_correction"] + k["write_size_kib"]) * k["launches_per_step"]
+            return int(total * 1024)
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None
 
 
 def cpu_quota():
@@ -169,7 +171,17 @@ def parse_args():
     ap.add_argument("--variant", type=int, default=-1, help="force a kernel specialisation")
     ap.add_argument("--target-width", type=float, default=0.0, help="override the workload's target_width (tuning: other kernel lengths)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=0|1",
+                    help="pin one of the library's alternative code paths for a same-session A/B (pdog_set_tuning), e.g. --tuning no_fold=1")
+    ap.add_argument("--no-exact", action="store_true", help="exact mode off (pdog_set_exact(t, 0)): the raw FP32 ranking, for the A/B of its cost")
     ap.add_argument("--data-rank", type=int, default=-1, help="generate the synthetic data of this rank (checks the per-rank seeds on one GPU)")
+    ap.add_argument("--chain", action="store_true",
+                    help="the SERIAL chain of src/PawsomeTracker.jl:163-169 instead of independent windows: the workload's batch is ONE clip of "
+                         "that many frames, frame k searched around frame k-1's answer (pdog_detect_chain: one launch per clip); a step = one clip; "
+                         "cpu_baseline = the oracle walking the same chain")
+    ap.add_argument("--group-total", type=int, default=0,
+                    help="--group only: total windows over the group (default batch x gpus); a total that is not a multiple of the group "
+                         "size gives shards that differ by one window and exercises the compaction of the gathered blocks")
     ap.add_argument("--group", action="store_true",
                     help="N GPUs from ONE process through the C ABI's pdog_group_* (in-process RCCL ncclGather) instead of one process per GPU")
     return ap.parse_args()
@@ -228,7 +240,7 @@ def result_line(args, desc, world, dt, kern_ms, batch, info, kernel_for_batch, f
                      "note": "path is FP32-VALU bound (375 flop/B vs ridge 19.7, DESIGN.md); achieved = algorithmic bytes of one "
                              "step / the step's kernel time (HIP events on the launch stream: every kernel of the step); "
                              "traffic = FETCH_SIZE (x2 gfx950 correction where the kernel reads 16 B/lane) + WRITE_SIZE of every "
-                             "kernel of a step, profiles/traffic_r02.json; the chip sustains ~2.0 GHz under this kernel, "
+                             "kernel of a step, profiles/traffic_r03.json; the chip sustains ~2.0 GHz under this kernel, "
                              "valu.peak is quoted at the nominal 2.4 GHz"},
     }
 
@@ -245,12 +257,13 @@ def run_group(args):
         batch = args.batch
     ws = pt.fix_window_size(ws if not isinstance(ws, tuple) else (ws[1], ws[0]))
     radii = (ws[0] // 2, ws[1] // 2)
-    n_total = batch * world
+    n_total = args.group_total if args.group_total > 0 else batch * world
+    sizes = [pt.shard_range(n_total, r, world) for r in range(world)]
     frames, guesses, guesses_h, centres = [], [], [], []
     fill = 128
     for r in range(world):
         dev = torch.device("cuda", r)
-        f, g_h, c = make_frames(torch, batch, fh, fw, tw, radii, seed=1000 * r, noise=args.noise, device=dev)
+        f, g_h, c = make_frames(torch, sizes[r][1] - sizes[r][0], fh, fw, tw, radii, seed=1000 * r, noise=args.noise, device=dev)
         if r == 0 and args.noise:
             fill = pt.mode(f[0].cpu().numpy())
         frames.append(f)
@@ -259,7 +272,7 @@ def run_group(args):
         centres.append(c)
     with native_stdout_to_stderr():
         gt = pt.GroupTracker(list(range(world)), fh, fw, tw, ws, True, fill)
-    assert all(gt.shard(n_total, r) == (r * batch, (r + 1) * batch) for r in range(world))
+    assert all(gt.shard(n_total, r) == tuple(sizes[r]) for r in range(world))
     gt.reserve(n_total)
     info = gt.info(0)
     out = torch.empty((n_total, 2), dtype=torch.int32, device="cuda:0")
@@ -289,8 +302,113 @@ def run_group(args):
     res = result_line(args, desc, world, dt, kern_ms, batch, info, gt.kernel_for_batch(batch), fh, fw, tw,
                       f"frames x{world} from one process (pdog_group_*), in-process RCCL ncclGather of int32[n,2] to device 0")
     res["roofline"]["note"] += "; group mode: kernel_ms = rank 0's kernels + its part of the gather"
+    if args.group_total > 0:
+        res["value"] = n_total * args.steps / dt
+        res["config"]["group_total"] = n_total
+        res["config"]["shard_sizes"] = [hi - lo for lo, hi in sizes]
     print(json.dumps(res))
     gt.close()
+    return 0
+
+
+def make_clip(np, n, h, w, tw, radii, seed, noise):
+    """One synthetic clip: a dark disc walking an Archimedean spiral out of the frame centre in steps of a few pixels
+    (the reference's test trajectory, test/test-basic-test.jl:23-41, without its unseeded jitter), +-noise levels."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rad = int(tw) // 2
+    k = np.arange(n)
+    step = min(radii) / 4.0                                     # arc length per frame: well inside the search window
+    theta = np.sqrt(2.0 * step * k / 3.0 + 1.0)                  # r = 3·theta: ds ≈ r·dtheta
+    r = np.minimum(3.0 * theta, min(h, w) / 2.0 - rad - 2)
+    ci = np.rint(h / 2 + r * np.sin(theta)).astype(np.int64)
+    cj = np.rint(w / 2 + r * np.cos(theta)).astype(np.int64)
+    yy, xx = np.mgrid[0:h, 0:w]
+    frames = np.full((n, h, w), 128, np.uint8)
+    for f in range(n):
+        frames[f][(yy - ci[f]) ** 2 + (xx - cj[f]) ** 2 <= rad * rad] = 0
+    if noise:
+        frames = np.clip(frames.astype(np.int16) + rng.integers(-noise, noise + 1, frames.shape), 0, 255).astype(np.uint8)
+    return frames, np.stack([ci + 1, cj + 1], 1).astype(np.int32)   # 1-based centres
+
+
+def run_chain(args):
+    """cfg1 as BASELINE.json states it: ONE clip walked serially (src/PawsomeTracker.jl:163-169) — frame k's window is
+    centred on frame k-1's answer.  Frames resident in HBM, one pdog_detect_chain launch per clip; the CPU port walks the same
+    chain with the oracle's dense Float64 functor, threaded inside the window like the reference's CPUThreads call."""
+    import numpy as np
+    import torch
+    import pawsometracker_jl_amd as pt
+    fh, fw, tw, ws, n_frames, desc = WORKLOADS[args.workload]
+    if args.batch:
+        n_frames = args.batch
+    if args.target_width:
+        tw, desc = args.target_width, desc + f" [target_width overridden: {args.target_width}]"
+    ws = pt.fix_window_size(ws if not isinstance(ws, tuple) else (ws[1], ws[0]))
+    radii = (ws[0] // 2, ws[1] // 2)
+    frames_h, centres = make_clip(np, n_frames, fh, fw, tw, radii, seed=0, noise=args.noise)
+    fill = pt.mode(frames_h[0])
+    dev = torch.device("cuda", 0)
+    frames = torch.from_numpy(frames_h).to(dev)
+    start = (int(centres[0, 0]), int(centres[0, 1]))
+    bt = pt.BatchTracker(fh, fw, tw, ws, True, fill, device=0)
+    bt.use_torch_stream()
+    info = bt.info()
+    out = torch.empty((n_frames, 2), dtype=torch.int32, device=dev)
+    for _ in range(args.warmup):
+        bt.detect_chain(frames, start, out=out)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    refined0 = bt.exact_stats()[2]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        bt.detect_chain(frames, start, out=out)
+        ev[k][1].record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    got = out.cpu().numpy()
+    err = np.abs(got - centres).max()
+    if not os.environ.get("PDOG_BENCH_NOCHECK"):
+        assert err <= (1 if args.noise else 0), f"chain lost the target: max |pos - centre| = {err}"
+    res = result_line(args, desc + f" [--chain: one clip of {n_frames} frames walked serially]", 1, dt, kern_ms, n_frames, info, "chain", fh, fw, tw,
+                      "single GPU, one clip (a serial chain does not shard: replicas only)")
+    res["config"]["chain"] = True
+    res["roofline"]["note"] = ("serial chain: one workgroup walks the clip, so this line is LATENCY (us per frame = ms_per_step * 1000 / frames), "
+                               "not throughput; achieved/valu are the clip's algorithmic bytes and FMAs over the clip's time. " + res["roofline"]["note"])
+    res["us_per_frame"] = dt / args.steps / n_frames * 1e6
+    on, thr, refined1 = bt.exact_stats()
+    res["exact"] = {"on": on, "threshold_2delta": thr, "refined_windows_per_step": (refined1 - refined0) / args.steps}
+    if not args.no_cpu:
+        from oracle.dog_oracle import Oracle, build
+        build()
+        o, strict = Oracle(fast=True), Oracle(fast=False)
+        K = strict.dog_kernel(strict.sigma(tw), True)
+        quota = cpu_quota()
+        cores = max(1, min(o.max_threads(), int(quota))) if quota else o.max_threads()
+        best = {}
+        for label, nt in (("threads_within_window", cores), ("single_thread", 1)):
+            g, pos = start, []
+            o.detect(frames_h[0], fill, K, radii, g, nthreads=nt)   # warm the thread pool
+            t1 = time.perf_counter()
+            for f in range(n_frames):
+                g = o.detect(frames_h[f], fill, K, radii, g, nthreads=nt)
+                pos.append(g)
+            best[label] = (n_frames / (time.perf_counter() - t1), np.array(pos, np.int32))
+        for label, (_, pos) in best.items():
+            assert np.array_equal(pos, got), f"GPU chain differs from the CPU oracle's chain ({label})"
+        L = info.kernel_len
+        val = max(v for v, _ in best.values())
+        res["cpu_baseline"] = {
+            "value": val, "unit": "frames/s", "cores": cores if best["threads_within_window"][0] >= best["single_thread"][0] else 1,
+            "cgroup_cpu_quota": quota, "host_threads_visible": o.max_threads(), "kind": "port",
+            "sample": f"the same {n_frames}-frame clip walked serially by the oracle (oracle/dog_oracle.c, -Ofast): dense {L}x{L} Float64 correlation + "
+                      "first-max argmax per frame, each frame searched around the previous answer; value = the faster of threading inside the window "
+                      f"(the reference's CPUThreads model, {cores} threads) and one thread; positions equal to the GPU's on every frame",
+            "threads_within_window": {"value": best["threads_within_window"][0], "threads": cores},
+            "single_thread": {"value": best["single_thread"][0], "threads": 1}}
+    print(json.dumps(res))
+    bt.close()
     return 0
 
 
@@ -307,6 +425,11 @@ def main():
         print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible on this node "
               "(RCCL needs one device per rank; PDOG_BENCH_BACKEND=gloo rehearses the control flow on fewer)", file=sys.stderr)
         return 2
+    if args.chain:
+        if args.gpus != 1 or env_world not in (None, "1"):
+            print("bench.py: --chain walks ONE clip serially; a serial chain does not shard (replicas only): use --gpus 1", file=sys.stderr)
+            return 2
+        return run_chain(args)
     if args.group:
         if env_world not in (None, "1"):
             print("bench.py: --group drives every GPU from ONE process; do not start it under torch.distributed.run", file=sys.stderr)
@@ -355,6 +478,11 @@ def main():
     bt = pt.BatchTracker(fh, fw, tw, ws, True, fill, device=dev_index)
     if args.variant >= 0:
         bt.set_variant(args.variant)
+    for kv in args.tuning:
+        key, _, val = kv.partition("=")
+        bt.set_tuning(key, int(val or 1))
+    if args.no_exact:
+        bt.set_exact(0)
     bt.reserve(batch)
     bt.use_torch_stream()
     info = bt.info()

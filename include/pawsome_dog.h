@@ -129,6 +129,17 @@ int pdog_sync(pdog_tracker *t);
  * computation on the device: a self-check, orders of magnitude slower).  pdog_get_exact: state, the threshold 2 delta, and how many windows have been re-evaluated
  * since the tracker was created (any of the out pointers may be NULL; reading the count drains the stream). */
 int pdog_set_exact(pdog_tracker *t, int on);
+/* Pins one of the library's alternative code paths on a live tracker — for tests and same-session A/B, not for a host:
+ * the defaults are the measured-best choices.  The library reads NO path switch from the environment (only resource
+ * limits: PDOG_SCRATCH_MB, PDOG_MAP_MB, PDOG_HOST_THREADS, PDOG_INGEST_CHUNK, once at pdog_create).  Keys (value 0 / 1):
+ *   "host_copy"    pdog_detect_host uploads the tile with copy commands instead of reading it in place
+ *   "host_sync"    … reads in place but waits with a stream synchronise instead of the ticket
+ *   "twopass_4l"   the two-pass kernels always in their four-launch form
+ *   "no_tiled"     single large windows on the two-pass launches instead of the tiled kernel
+ *   "no_roll_map"  hard batches keep recomputing their refinement candidates
+ *   "no_fold" / "fold_always"  a single remainder column always / never goes to the remainder-column kernel
+ * Unknown key: PDOG_E_ARG.  Drains the tracker's stream. */
+int pdog_set_tuning(pdog_tracker *t, const char *key, int value);
 int pdog_get_exact(pdog_tracker *t, int *out_on, double *out_threshold, uint64_t *out_refined);
 /* Where the re-evaluation's work went since the tracker was created: out[0] windows refined, out[1] column blocks
  * rescanned in FP32, out[2] candidates evaluated in separable Float64, out[3] sequential dense Float64 chains run
@@ -240,7 +251,11 @@ int pdog_shard_owner(int n_total, int ndev, int window, int *rank, int *local_in
 int pdog_group_detect_batch(pdog_group *g, const uint8_t *const *d_frames, int64_t frame_stride,
                             int64_t row_stride, const int *n_frames, const int32_t *const *d_frame_index,
                             const int32_t *const *d_guesses, int n_total, int32_t *d_out_ij);
+/* Waits for EVERY rank (each rank's raised flags are reported and cleared); returns the first error. */
 int pdog_group_sync(pdog_group *g);
+/* Test hook: runs the copy kernel that compacts the gathered blocks of unequal shards (d_gathered: int32[ndev][⌈n_total/ndev⌉][2],
+ * d_out: int32[n_total][2], both on the current device) — the one step of pdog_group_detect_batch a one-GPU box cannot reach. */
+int pdog_group_test_compact(const int32_t *d_gathered, int n_total, int ndev, int32_t *d_out);
 
 #ifdef __cplusplus
 }

@@ -20,8 +20,8 @@ SYMBOLS = (
     "pdog_detect_batch", "pdog_detect_host", "pdog_window_tile", "pdog_detect_batch_host", "pdog_detect_chain", "pdog_detect_chains",
     "pdog_alloc_host", "pdog_free_host", "pdog_detect_chain_progress", "pdog_get_stream",
     "pdog_group_create", "pdog_group_destroy", "pdog_group_size", "pdog_group_tracker", "pdog_group_shard",
-    "pdog_group_detect_batch", "pdog_group_sync", "pdog_shard_range", "pdog_shard_owner",
-    "pdog_set_exact", "pdog_get_exact", "pdog_get_exact_detail", "pdog_dense_kernel",
+    "pdog_group_detect_batch", "pdog_group_sync", "pdog_shard_range", "pdog_shard_owner", "pdog_group_test_compact",
+    "pdog_set_exact", "pdog_get_exact", "pdog_get_exact_detail", "pdog_dense_kernel", "pdog_set_tuning",
 )
 
 
@@ -123,8 +123,10 @@ def lib():
         L.pdog_group_sync.restype = i; L.pdog_group_sync.argtypes = [p]
         L.pdog_shard_range.restype = i; L.pdog_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
         L.pdog_shard_owner.restype = i; L.pdog_shard_owner.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
+        L.pdog_group_test_compact.restype = i; L.pdog_group_test_compact.argtypes = [p, i, i, p]
     if hasattr(L, "pdog_dense_kernel"):
         L.pdog_dense_kernel.restype = i; L.pdog_dense_kernel.argtypes = [d, i, p, i]
+    L.pdog_set_tuning.restype = i; L.pdog_set_tuning.argtypes = [p, C.c_char_p, i]
     if hasattr(L, "pdog_set_exact"):
         L.pdog_set_exact.restype = i; L.pdog_set_exact.argtypes = [p, i]
         L.pdog_get_exact.restype = i; L.pdog_get_exact.argtypes = [p, C.POINTER(i), C.POINTER(d), C.POINTER(C.c_uint64)]

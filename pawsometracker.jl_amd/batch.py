@@ -33,6 +33,10 @@ class BatchTracker:
         """Exact mode (default on): near-ties of the FP32 ranking are re-decided in the reference's Float64 arithmetic."""
         _lib.check(_lib.lib().pdog_set_exact(self._h, int(on)))   # 0 off, 1 on, 2 re-evaluate everything (self-check)
 
+    def set_tuning(self, key, value=1):
+        """Pin one of the library's alternative code paths (pdog_set_tuning): tests and A/B only."""
+        _lib.check(_lib.lib().pdog_set_tuning(self._h, key.encode(), int(value)))
+
     def exact_stats(self):
         """(on, threshold 2δ, windows re-evaluated so far) — pdog_get_exact."""
         on, thr, n = C.c_int(), C.c_double(), C.c_uint64()
@@ -200,13 +204,15 @@ class ChainProgress:
         drained first — unless the tracker itself is already closed (pdog_destroy drains its stream)."""
         if self._out_ptr is None and self._prog_ptr is None:
             return
-        if getattr(self._bt, "_h", None):
-            self._bt.sync()
-        self.positions = self._prog = None
-        for ptr in (self._out_ptr, self._prog_ptr):
-            if ptr is not None:
-                _lib.lib().pdog_free_host(ptr)
-        self._out_ptr = self._prog_ptr = None
+        try:
+            if getattr(self._bt, "_h", None):
+                self._bt.sync()          # may raise what the chain's kernels raised: the buffers go back regardless
+        finally:
+            self.positions = self._prog = None
+            for ptr in (self._out_ptr, self._prog_ptr):
+                if ptr is not None:
+                    _lib.lib().pdog_free_host(ptr)
+            self._out_ptr = self._prog_ptr = None
 
     def __del__(self):
         try:

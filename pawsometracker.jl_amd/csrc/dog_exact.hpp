@@ -789,7 +789,28 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
         if (b < g.n) {
             Peak pk;
             peak_init(pk);
-            for (int s = lane; s < g.nslots; s += 64) peak_merge(pk, g.part_val[b * g.nslots + s], g.part_idx[b * g.nslots + s], g.part_sec[b * g.nslots + s]);
+            int nload = g.nslots;
+            if (g.fold_r) {
+                // Folded remainder column (dog_roll.hpp): the last strip left the row-pass outputs of window column thin_x0;
+                // its column pass runs here, one output row per lane and round, in the strips' operation order (per tap t
+                // ascending, the g+ term then the g− term into one f32) ⇒ bit-identical to what a strip would have produced.
+                const int NA = g.n1 + g.L - 1, NAP = NA + FOLD_GO; // slice pitch: the sliding windows of the last lanes read a few entries past NA
+                f2 *Rc = reinterpret_cast<f2 *>(smem) + (size_t)wave * NAP; // wave-private
+                const f2 *src = g.fold_r + (long long)b * NA;
+                for (int a = lane; a < NAP; a += 64) Rc[a] = a < NA ? src[a] : f2{0.f, 0.f};
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                Peak tp = fold_column_peak(Rc, g.n1, g.L, as_taps(taps_col), g.thin_x0 * g.n1, lane);
+                nload = fg.nmain; // the column's slot is filled here, not read
+                if (lane == 0) {
+                    pk = tp;
+                    g.part_val[b * g.nslots + fg.nmain] = tp.best; // the refinement reads the slots' maxima from memory
+                    g.part_idx[b * g.nslots + fg.nmain] = tp.idx;
+                    g.part_sec[b * g.nslots + fg.nmain] = tp.second;
+                }
+            }
+            for (int s = lane; s < nload; s += 64) peak_merge(pk, g.part_val[b * g.nslots + s], g.part_idx[b * g.nslots + s], g.part_sec[b * g.nslots + s]);
             peak_wave_reduce(pk);
             if (lane == 0) {
                 const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];

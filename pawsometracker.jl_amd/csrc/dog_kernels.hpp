@@ -85,19 +85,27 @@ struct ExactCtl {
 // The reference's PaddedView extends radii + l past the frame (:45-46) and the filter reads radii + l÷2 around the
 // guess: a guess outside [−l÷2, sz + l÷2 + 1] raises BoundsError there.  Device-resident guesses cannot be checked
 // before the launch, so the kernels raise a flag that pdog_sync reports.
-// Bounded wait for a device-scope counter that other resident workgroups advance (dog_tiled.hpp, dog_coop.hpp): every wave
-// that waits reaches an exit — after ≈1 s without progress the wait gives up, raises the fault value 2 in the host-coherent
-// word (pdog_sync then reports PDOG_E_HIP) and the kernel runs on to its end with whatever it has.  Returns false on give-up.
-__device__ __forceinline__ bool wait_counter(const unsigned *ctr, unsigned target, const ExactCtl &x)
+// Bounded wait for a device-scope counter that other resident workgroups advance (dog_tiled.hpp): every wave that waits
+// reaches an exit.  The bound is WALL time (s_memrealtime, 100 MHz): after ≈1 s without progress the wait gives up, raises
+// `abort` (a device word every other wait polls, so the peers give up within microseconds instead of a second each) and the
+// fault value 2 in the host-coherent word (pdog_sync then reports PDOG_E_HIP and zeroes the control words).  Returns false on
+// give-up or when a peer has given up: the caller leaves its frame loop without publishing anything further.
+constexpr unsigned long long WAIT_TICKS = 100000000ull; // 1 s of s_memrealtime
+__device__ __forceinline__ bool wait_counter(const unsigned *ctr, unsigned target, const ExactCtl &x, unsigned *abort)
 {
-    for (unsigned spins = 0; __hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned spins = 1; __hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
         __builtin_amdgcn_s_sleep(1);
-        if (spins > (1u << 24)) {
-            if (x.range_err) __hip_atomic_store(x.range_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            return false;
+        if ((spins & 63u) == 0u) {
+            if (abort && __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false; // a peer gave up
+            if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_TICKS) {
+                if (abort) __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (x.range_err) __hip_atomic_store(x.range_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return false;
+            }
         }
     }
-    return true;
+    return !(abort && __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
 __device__ __forceinline__ void range_check(const ExactCtl &x, int g1, int g2, int hw, int fh, int fw)
@@ -122,7 +130,51 @@ struct LaunchGeo {
     int nblocks;                         // n * nstrips
     int nslots;                          // partials per window: nstrips + thin columns
     int thin_x0, nthin;                  // window columns [thin_x0, thin_x0+nthin) go to dog_thin_kernel
+    // FOLDED remainder column (dog_roll.hpp): nthin == 1 and fold_r != null ⇒ no dog_thin_kernel launch; the last strip of
+    // every window also produces the row-pass outputs (R+, R−) of window column thin_x0 and leaves them here,
+    // [n][n1 + L − 1]; dog_finish_kernel runs that one column's column pass.  Same operation order as a strip: the column's
+    // values are bit-identical to what a strip would have produced.
+    f2 *__restrict__ fold_r;
 };
+
+constexpr int FOLD_GO = 5; // output rows per lane and pass of a folded remainder column (257 rows = 64 lanes × 5 + 1 …)
+// Column pass + peak of ONE window column whose row-pass outputs Rc[0 … n1 + L − 2] (+ FOLD_GO readable entries of padding) sit
+// in LDS, by one wave: a lane owns Q = ⌈n1 / 64⌉ consecutive output rows, FOLD_GO at a time through a sliding register window —
+// one LDS read and one scalar tap load per tap feed 2·FOLD_GO FMAs.  Per output: taps ascending, the g+ term then the g− term
+// into one f32 — the strips' order.  The peak (best, first column-major index, runner-up) is valid in lane 0 on return.
+__device__ __forceinline__ Peak fold_column_peak(const f2 *Rc, int n1, int L, tap_ptr tcol, int lin0, int lane)
+{
+    Peak tp;
+    peak_init(tp);
+    const int Q = (n1 + 63) / 64;
+    for (int q0 = 0; q0 < Q; q0 += FOLD_GO) {
+        const int y0 = lane * Q + q0;
+        const int nv = max(0, min(min(FOLD_GO, Q - q0), n1 - y0)); // valid outputs of this lane in this group
+        const f2 *rp = Rc + (nv > 0 ? y0 : 0);
+        float acc[FOLD_GO];
+        f2 win[FOLD_GO];
+#pragma unroll
+        for (int j = 0; j < FOLD_GO; ++j) { acc[j] = 0.f; win[j] = rp[j]; }
+#pragma unroll 5
+        for (int t = 0; t < L; ++t) {
+            const f2 w = tcol[t];
+            const f2 nxt = rp[t + FOLD_GO];
+#pragma unroll
+            for (int j = 0; j < FOLD_GO; ++j) {
+                acc[j] = __builtin_fmaf(win[j].x, w.x, acc[j]);
+                acc[j] = __builtin_fmaf(win[j].y, w.y, acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j + 1 < FOLD_GO; ++j) win[j] = win[j + 1];
+            win[FOLD_GO - 1] = nxt;
+        }
+#pragma unroll
+        for (int j = 0; j < FOLD_GO; ++j)
+            if (j < nv) peak_push(tp, acc[j], lin0 + y0 + j);
+    }
+    peak_wave_reduce(tp);
+    return tp;
+}
 
 __host__ __device__ constexpr int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // LDS row pitches.  A (f32 input tile) is read by lanes that sit in consecutive

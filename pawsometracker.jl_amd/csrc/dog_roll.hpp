@@ -44,6 +44,10 @@ constexpr int ROLL_LMIN = 17, ROLL_LMAX = PDOG_ROLL_LMAX; // kernel lengths with
                                               // windows and the loop state fit 168 VGPRs up to l = 81 (three waves per SIMD) and 256 up to l = 97
                                               // (two); longer kernels go to dog_twopass.hpp (round 2's l = 101 / 105 instances spilled and lost to it)
 __host__ __device__ constexpr int roll_waves(int L) { return L <= 81 ? 3 : 2; } // waves per SIMD the instance is compiled for
+// Kernel lengths whose instances can FOLD a single remainder column into the last strip (LaunchGeo::fold_r).  The second
+// row-pass variant costs ≈18 VGPRs: l = 65 (the reference's default target_width) absorbs them inside its three-waves budget
+// (163 of 168); the neighbouring lengths would lose a wave per SIMD to it and keep dog_thin_kernel instead.
+__host__ __device__ constexpr bool roll_folds(int L) { return L == 65; }
 
 // accumulator slots: the l outputs in flight plus the sub-chunk being emitted, rounded so that the
 // slot ↔ tap mapping repeats after a whole number of sub-chunks
@@ -85,19 +89,23 @@ __device__ __forceinline__ tap_ptr pin_taps(tap_ptr p)
 // a = &A[r][P*gx] (16-byte aligned); inputs a[0 .. P+L-2].  Taps ascending k = 0..H-1, centre last: same order for
 // every output, so equal inputs give bit-equal outputs.
 typedef float f4 __attribute__((ext_vector_type(4)));
-template <int L>
-__device__ __forceinline__ void roll_row_pass(f2 (&acc)[ROLL_P], const float *a, tap_ptr taps)
+// NOUT = 9: the lane also computes output 8 — for the last lane group of a FOLDED strip that is window column 64·k of a
+// window 64·k + 1 columns wide (257, 513, …), the column round 2 gave to dog_thin_kernel.  The odd taps already hold its
+// pair sums (the outer half of their fifth v_pk_add_f32), the even taps add one: +49 packed instructions per sub-chunk
+// in the one strip per window that folds, instead of a second kernel re-reading a 65-column patch per window.
+template <int L, int NOUT = ROLL_P>
+__device__ __forceinline__ void roll_row_pass(f2 (&acc)[NOUT == ROLL_P ? ROLL_P : ROLL_P + 2], const float *a, tap_ptr taps)
 {
     constexpr int P = ROLL_P, H = L / 2, U = 4, NB = (H + U - 1) / U, HQ = H / 2;
-    static_assert(P == 8 && H % 2 == 0, "the pairing below is written for 8 outputs and L = 4m + 1");
+    constexpr int NHI = (NOUT == P) ? 3 : 4, ME = (NOUT == P) ? 4 : 5; // hi-window quads; pair sums per even tap
+    static_assert(P == 8 && (NOUT == 8 || NOUT == 9) && H % 2 == 0, "the pairing below is written for 8 (+1) outputs and L = 4m + 1");
     auto quad = [&](int q) { return *reinterpret_cast<const f4 *>(a + 4 * q); };
     auto half = [](const f4 &v, int h) { return h ? __builtin_shufflevector(v, v, 2, 3) : __builtin_shufflevector(v, v, 0, 1); };
-    f4 lw[3], hw[3]; // quads J … J+2 and HQ−J−1 … HQ−J+1
+    f4 lw[3], hw[NHI]; // quads J … J+2 and HQ−J−1 … HQ−J−2+NHI
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        lw[j] = quad(j);
-        hw[j] = quad(HQ - 1 + j);
-    }
+    for (int j = 0; j < 3; ++j) lw[j] = quad(j);
+#pragma unroll
+    for (int j = 0; j < NHI; ++j) hw[j] = quad(HQ - 1 + j);
     f2 tn[U];
     tap_ptr tb = pin_taps(taps); // ONE base re-pinned in place per block: the loads below keep constant offsets from it
 #pragma unroll                   // (an opaque pointer per block made 9 loop-invariant address pairs, all spilled to VGPR lanes)
@@ -129,35 +137,37 @@ __device__ __forceinline__ void roll_row_pass(f2 (&acc)[ROLL_P], const float *a,
                 const int k = k0 + u;
                 if ((k & 1) == 0) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
+                    for (int m = 0; m < ME; ++m) {
                         const f2 s2 = LO(k / 2 + m) + HI(H - k / 2 + m);
                         acc[2 * m] = fma_bcast(s2.x, t[u], acc[2 * m]);
-                        acc[2 * m + 1] = fma_bcast(s2.y, t[u], acc[2 * m + 1]);
+                        if (m < 4) acc[2 * m + 1] = fma_bcast(s2.y, t[u], acc[2 * m + 1]);
                     }
                 } else {
 #pragma unroll
                     for (int m = 0; m < 5; ++m) {
                         const f2 s2 = LO((k - 1) / 2 + m) + HI(H - (k + 1) / 2 + m);
                         if (m >= 1) acc[2 * m - 1] = fma_bcast(s2.x, t[u], acc[2 * m - 1]);
-                        if (m <= 3) acc[2 * m] = fma_bcast(s2.y, t[u], acc[2 * m]);
+                        if (m <= 3 || NOUT == 9) acc[2 * m] = fma_bcast(s2.y, t[u], acc[2 * m]);
                     }
                 }
             }
         }
         if (more) {
             lw[0] = lw[1]; lw[1] = lw[2]; lw[2] = nl;
-            hw[2] = hw[1]; hw[1] = hw[0]; hw[0] = nh;
-        } else {
-            // centre tap: a[o + H], the pairs E[HQ … HQ+3] — inside the last lo window whatever H mod 4 is
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const f2 c2 = LO(HQ + m);
+            for (int j = NHI - 1; j > 0; --j) hw[j] = hw[j - 1];
+            hw[0] = nh;
+        } else {
+            // centre tap: a[o + H], the pairs E[HQ … HQ+3 (+1)] — inside the last hi window whatever H mod 4 is
+#pragma unroll
+            for (int m = 0; m < ME; ++m) {
+                const f2 c2 = HI(HQ + m);
                 acc[2 * m] = fma_bcast(c2.x, tn[0], acc[2 * m]);
-                acc[2 * m + 1] = fma_bcast(c2.y, tn[0], acc[2 * m + 1]);
+                if (m < 4) acc[2 * m + 1] = fma_bcast(c2.y, tn[0], acc[2 * m + 1]);
             }
         }
 #pragma unroll
-        for (int o = 0; o < P; ++o) pin_acc(acc[o]);
+        for (int o = 0; o < NOUT; ++o) pin_acc(acc[o]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -315,6 +325,20 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
         }
     };
 
+    // ---- folded remainder column (LaunchGeo::fold_r): the last strip's row pass also produces window column 64·nstrips.
+    // Its last input is strip column TW + L − 1; where the 8·SB staged columns end one short of it (l = 33, 65, 97, 129)
+    // the lanes of the last segment stage that one byte more, into the slack of the A row ----
+    constexpr bool FOLD_OK = !RESP && ABL == 0 && roll_folds(L);
+    constexpr bool FOLD_EXTRA = (8 * SB < TW + L);
+    const bool fold = FOLD_OK && g.fold_r != nullptr && s == g.nstrips - 1; // wave-uniform
+    const int xcol = tj0 + 8 * SB;                                          // frame col of the extra byte
+    auto load_extra = [&](int a_row) -> uint32_t {
+        const int gi = ti0 + a_row;
+        uint32_t v = (uint32_t)g.fill;
+        if (sseg == SEGS - 1 && a_row < NA && gi >= 0 && gi < g.fh && xcol >= 0 && xcol < g.fw) v = frame[(long long)gi * g.row_stride + xcol];
+        return v;
+    };
+
     f2 acc2[S / 2];
 #pragma unroll
     for (int j = 0; j < S / 2; ++j) acc2[j] = f2{0.f, 0.f};
@@ -328,6 +352,8 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
     if (ABL & 16) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
     uint32_t pre[SB / 4];
     load16(srow, pre);
+    uint32_t pre_x = 0;
+    if (FOLD_EXTRA && fold) pre_x = load_extra(srow);
     const int nsub = (NA + CH - 1) / CH;
     const int rr = lane & 7, rgx = lane >> 3; // row-pass task: row rr, output group rgx
     const long long resp_base = (long long)b * g.n1 * g.n2;
@@ -344,6 +370,10 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
                 const f2 v23 = f2{(float)((word >> 16) & 0xffu), (float)(word >> 24)} + ndc;
                 *reinterpret_cast<f4 *>(dst + 4 * q) = f4{v01.x, v01.y, v23.x, v23.y};
             }
+            if (FOLD_EXTRA && fold) {
+                if (sseg == SEGS - 1) A[roll_row_base(srow, L) + 8 * SB] = (float)pre_x - (float)dc;
+                pre_x = load_extra((sc + 1) * CH + srow);
+            }
             if (!(ABL & 8)) load16((sc + 1) * CH + srow, pre);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -351,13 +381,23 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // ---- row pass: rounds of 8 rows × 8 groups of 8 outputs ----
         if (!(ABL & 2)) {
-#pragma unroll 1
-            for (int h = 0; h < RPASS; ++h) {
+            static_assert(RPASS == 1, "one row-pass round per sub-chunk");
+            const float *arow = A + roll_row_base(rr, L) + rgx * P;
+            f2 *dst = Rb + rr * ROLL_PR + rgx * P;
+            if (FOLD_OK && fold) {
+                f2 racc[P + 2];
+#pragma unroll
+                for (int o = 0; o < P + 2; ++o) racc[o] = f2{0.f, 0.f};
+                roll_row_pass<L, P + 1>(racc, arow, trow);
+#pragma unroll
+                for (int o = 0; o < P; ++o) dst[o] = racc[o];
+                // the last lane group's ninth output is window column 64·nstrips of input row sc·8 + rr
+                if (rgx == TW / P - 1 && sc * CH + rr < NA) g.fold_r[(long long)b * NA + sc * CH + rr] = racc[P];
+            } else {
                 f2 racc[P];
 #pragma unroll
                 for (int o = 0; o < P; ++o) racc[o] = f2{0.f, 0.f};
-                roll_row_pass<L>(racc, A + roll_row_base(rr + 8 * h, L) + rgx * P, trow);
-                f2 *dst = Rb + (rr + 8 * h) * ROLL_PR + rgx * P;
+                roll_row_pass<L>(racc, arow, trow);
 #pragma unroll
                 for (int o = 0; o < P; ++o) dst[o] = racc[o];
             }
@@ -483,9 +523,13 @@ __device__ __attribute__((noinline)) void roll_strip_call(const LaunchGeo *gp, c
     *mask = m;
 }
 
+// One strip per workgroup (one wave).  Tried in round 3: up to four strips of ONE window per workgroup, a wave each (still no
+// barrier), so that the strips of a window — which read each other's halo columns — run on one CU at one time.  The HBM
+// traffic did not move (553.6 vs 557.6 MB per cfg3 step: the 1.31× over the algorithmic bytes is the fetch granularity on
+// unaligned 321-byte rows, not re-fetched halos) and cfg3 ran 2 % slower (cfg4 0.6 % faster): dropped.
 template <int LT, bool RESP, int ABL = 0, int EPI = -1>
 __global__ __launch_bounds__(64, roll_waves(LT)) void dog_roll_kernel(const LaunchGeo g, const f2 *__restrict__ taps_row,
-                                                         const f2 *__restrict__ taps_col)
+                                                                      const f2 *__restrict__ taps_col)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // XCD-aware block → (window, strip), see dog_kernels.hpp
@@ -643,8 +687,13 @@ __global__ __launch_bounds__(256) void dog_thin_kernel(const LaunchGeo g, const 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f2 *Rc = reinterpret_cast<f2 *>(smem);            // NA entries
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / g.nthin;
-    const int rc = blockIdx.x - b * g.nthin;
+    // XCD-aware block → (window, column) like the strips (dog_kernels.hpp): the kernel runs BESIDE the roll kernel, and a
+    // window's remainder column then meets its strips in one L2 — the patch it reads is the last strip's
+    const int nb = g.n * g.nthin, per_xcd = (nb + 7) >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= nb) return;
+    const int b = logical / g.nthin;
+    const int rc = logical - b * g.nthin;
     const int x = g.thin_x0 + rc;                     // window column
     const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
     const int fidx = g.frame_index ? g.frame_index[b] : b;

@@ -41,6 +41,8 @@ struct TiledGeo {
     int dc_host;            // ≥ 0: the window's DC level from the host (functor: see dog_fused.hpp); −1: sampled here
     int *cur;               // [n_clips][2]: the current guess, last arrival → everyone
     unsigned *sync;         // [n_clips][2], zero when a launch starts and when it ends: partial arrivals, frame flag (set after a refined frame only)
+    unsigned *abort;        // one word, zero unless a device-side wait of this tracker gave up (wait_counter): every wait polls it
+    int fault_inject;       // tests: sub-window 0 of clip 0 never delivers the partial of its second frame (pdog_set_tuning "fault_inject")
 };
 
 constexpr int TILED_SLOT_CAP = 256; // sub-windows per window the combining wave handles (4 per lane)
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
     __shared__ int s_sum[NW];
     __shared__ float s_val[NW], s_sec[NW];
     __shared__ int s_idx[NW];
-    __shared__ int s_last, s_refine;
+    __shared__ int s_last, s_refine, s_abort;
     __shared__ float s_max, s_sec2;
     __shared__ int s_idx2;
     __shared__ float s_pv[TILED_SLOT_CAP];
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
         for (int x = wave; x < m2; x += NW)
             for (int c = NAs + lane; c < tg.pitchV; c += 64) Vs[x * tg.pitchV + c] = f2{0.f, 0.f};
     };
+    if (tid == 0) s_abort = 0;
     zero_padding();
 
     int g1 = g.guesses[2 * clip], g2 = g.guesses[2 * clip + 1];
@@ -217,14 +220,16 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
                 __hip_atomic_store(&pi[par + s], pk.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&ps[par + s], pk.second, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned target = (unsigned)(k + 1) * (unsigned)nsub;
-                const unsigned old = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-                last = (old == target - 1u);
-                if (chain && !last)
-                    (void)wait_counter(arrive, target, g.ex);
+                const bool skip = tg.fault_inject && clip == 0 && s == 0 && k == 1; // (tests: a peer that never arrives)
+                const unsigned old = skip ? 0u : __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                last = !skip && (old == target - 1u);
+                if ((chain && !last) || skip)
+                    if (!wait_counter(arrive, skip ? ~0u : target, g.ex, tg.abort)) s_abort = 1; // gave up, or a peer did: leave the frame loop
             }
             last = __shfl(last, 0, 64);
+            const int aborted = __shfl(lane == 0 ? s_abort : 0, 0, 64);
             if (lane == 0) { s_last = last; s_refine = 0; }
-            if (last || chain) {
+            if ((last || chain) && !aborted) {
                 Peak w;
                 peak_init(w);
                 for (int sl = lane; sl < nsub; sl += 64) {
@@ -266,6 +271,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
             }
         }
         __syncthreads();
+        if (s_abort) break; // a device-side wait gave up: nothing further is written or published; pdog_sync reports PDOG_E_HIP
         if (s_refine) {
             if (s_last) { // a near-tie: the reference's own arithmetic decides (dog_exact.hpp); this workgroup's LDS is the scratch
                 const refine_params_ptr rp = (refine_params_ptr)(unsigned long long)tg.rp;
@@ -310,11 +316,12 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
             }
             if (k + 1 < tg.chain_len) { // the refined answer is the next guess (:167): it comes through the frame flag
                 if (tid == 0) {
-                    (void)wait_counter(flag, (unsigned)(k + 1), g.ex);
+                    if (!wait_counter(flag, (unsigned)(k + 1), g.ex, tg.abort)) s_abort = 1;
                     s_idx[0] = __hip_atomic_load(&cur[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_idx[1] = __hip_atomic_load(&cur[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 __syncthreads();
+                if (s_abort) break;
             }
         }
         if (k + 1 < tg.chain_len) { // :167

@@ -11,7 +11,6 @@
 #include "dog_twopass.hpp"
 #include "dog_fused.hpp"
 #include "dog_exact.hpp"
-#include "dog_coop.hpp"
 #include "dog_tiled.hpp"
 
 #include <cmath>
@@ -55,34 +54,46 @@ int fail(int code, const std::string &msg)
     return code;
 }
 
-// Run-time switches (DESIGN.md "Run-time switches"): the environment is read ONCE, when a tracker is created —
-// never on the launch path (a functor call's whole budget is ≈23 µs).
+// Run-time configuration.  The PRODUCT build reads four RESOURCE limits from the environment, once, when a tracker is
+// created (never on the launch path: a functor call's whole budget is ≈23 µs).  Everything that selects a code path is
+// either API (pdog_set_exact, pdog_set_variant, pdog_set_tuning — explicit, per tracker) or exists only in the diagnostic
+// build (make diag, -DPDOG_ABLATIONS), which also reads the tuning switches from the environment for tools/.
 struct Switches {
-    bool host_copy = false, host_sync = false, host_trace = false, twopass_4l = false, hpass16 = false;
-    bool ingest_no_nt = false, ingest_trace = false, fused_diag = false;
-    bool no_exact = false;                // PDOG_NO_EXACT: trackers start with exact mode off (A/B of its cost)
-    bool tiled_force = false;             // PDOG_TILED_FORCE: experiment — the tiled kernel also for windows the fused kernel serves
-    bool no_host_dc = false;              // PDOG_NO_HOST_DC: the functor's kernels sample the DC level themselves (A/B)
-    bool no_roll_map = false;             // PDOG_NO_ROLL_MAP: hard batches on the roll / ring kernels keep recomputing their candidates (A/B)
-    bool no_tiled = false;                // PDOG_NO_TILED: single large windows stay on the two-pass launches (A/B of the tiled kernel)
-    int tiled_sub = 0;                    // PDOG_TILED_SUB: sub-window edge of the tiled kernel (0: chosen per geometry)
-    int tp_ph1 = 0, tp_php = 0;           // PDOG_TP_P=ph1,php: outputs per task of the two-pass kernels (0: per geometry)
-    int v_after = 64;                     // PDOG_V_AFTER: exact mode, map path: first-scan candidates beyond which the window's own |pixel − dc| bound is computed
-    int h1_u = 4;                         // PDOG_H1_U: taps per block of the two-pass row pass (4, or 8)
-    int hp_u = 8;                         // PDOG_HP_U: taps per block of the two-pass column pass (8 or 16)
-    int tiled_batch = 2;                  // PDOG_TILED_BATCH: windows per batch up to which the tiled kernel is used
-    bool coop = false;                    // PDOG_COOP: single-clip chains of large windows as ONE cooperative launch (dog_coop.hpp; measured slower
-                                          // than the three stream-ordered launches per frame it replaces, so off by default)
-    size_t scratch_cap = (size_t)6 << 30; // HBM scratch of the two-pass intermediate; larger batches go in chunks
+    // resource limits (environment, product build)
+    size_t scratch_cap = (size_t)6 << 30; // PDOG_SCRATCH_MB: HBM scratch of the two-pass intermediate; larger batches go in chunks
     size_t map_cap = (size_t)4 << 30;     // PDOG_MAP_MB: largest FP32 response map the two-pass path keeps for exact mode (beyond: candidates are recomputed)
-    int fused_pr = 0, fused_pc = 0;       // PDOG_FUSED_P=pr,pc (0: chosen per geometry)
     int host_threads = 0;                 // PDOG_HOST_THREADS (0: min(16, cores))
     int ingest_chunk = 0;                 // PDOG_INGEST_CHUNK (0: ≈32 MB of tiles)
-    int lds_pad = 0;                      // PDOG_LDS_PAD (diagnostic build only)
+    // path selection (pdog_set_tuning; the tests exercise every alternative path of the product through it)
+    bool host_copy = false;               // functor: upload the tile with copy commands and synchronise the stream instead of the in-place tile + ticket
+    bool host_sync = false;               // functor: in-place tile, but wait with hipStreamSynchronize instead of polling the ticket
+    bool twopass_4l = false;              // two-pass path always in its four-launch form
+    bool no_tiled = false;                // single large windows stay on the two-pass launches
+    bool no_roll_map = false;             // hard batches on the roll / ring kernels keep recomputing their candidates
+    bool no_fold = false;                 // a single remainder column always goes to dog_thin_kernel
+    bool fold_always = false;             // … always into the last strip, also below 8 strips per window
+    bool fault_inject = false;            // tests: one sub-window of a tiled chain never delivers its second frame's partial (the device-side waits must give up)
+    // tuning and diagnosis (diagnostic build only)
+    bool host_trace = false, hpass16 = false, ingest_no_nt = false, ingest_trace = false, fused_diag = false;
+    bool tiled_force = false;             // the tiled kernel also for windows the fused kernel serves
+    bool no_host_dc = false;              // the functor's kernels sample the DC level themselves
+    int tiled_sub = 0;                    // sub-window edge of the tiled kernel (0: chosen per geometry)
+    int tp_ph1 = 0, tp_php = 0;           // outputs per task of the two-pass kernels (0: per geometry)
+    int v_after = 64;                     // exact mode, map path: first-scan candidates beyond which the window's own |pixel − dc| bound is computed
+    int h1_u = 4;                         // taps per block of the two-pass row pass (4, or 8)
+    int hp_u = 8;                         // taps per block of the two-pass column pass (8 or 16)
+    int tiled_batch = 2;                  // windows per batch up to which the tiled kernel is used
+    int fused_pr = 0, fused_pc = 0;       // outputs per task of the fused kernel (0: chosen per geometry)
+    int lds_pad = 0;                      // occupancy experiments
 };
 Switches read_switches()
 {
     Switches w;
+    if (const char *e = std::getenv("PDOG_SCRATCH_MB")) w.scratch_cap = (size_t)std::max(1, std::atoi(e)) << 20;
+    if (const char *e = std::getenv("PDOG_MAP_MB")) w.map_cap = (size_t)std::max(0, std::atoi(e)) << 20;
+    if (const char *e = std::getenv("PDOG_HOST_THREADS")) w.host_threads = std::max(1, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("PDOG_INGEST_CHUNK")) w.ingest_chunk = std::max(1, std::atoi(e));
+#ifdef PDOG_ABLATIONS
     auto on = [](const char *n) { return std::getenv(n) != nullptr; };
     w.host_copy = on("PDOG_HOST_COPY");
     w.host_sync = on("PDOG_HOST_SYNC");
@@ -92,9 +103,9 @@ Switches read_switches()
     w.ingest_no_nt = on("PDOG_INGEST_NO_NT");
     w.ingest_trace = on("PDOG_INGEST_TRACE");
     w.fused_diag = on("PDOG_FUSED_DIAG");
-    w.no_exact = on("PDOG_NO_EXACT");
-    w.coop = on("PDOG_COOP");
     w.no_tiled = on("PDOG_NO_TILED");
+    w.no_fold = on("PDOG_NO_FOLD");
+    w.fold_always = on("PDOG_FOLD_ALWAYS");
     w.no_roll_map = on("PDOG_NO_ROLL_MAP");
     w.no_host_dc = on("PDOG_NO_HOST_DC");
     w.tiled_force = on("PDOG_TILED_FORCE");
@@ -107,16 +118,13 @@ Switches read_switches()
         int a = 0, b = 0;
         if (std::sscanf(e, "%d,%d", &a, &b) == 2 && (a == 5 || a == 7 || a == 9 || a == 11 || a == 13 || a == 17) && (b == 5 || b == 7 || b == 9 || b == 13)) { w.tp_ph1 = a; w.tp_php = b; }
     }
-    if (const char *e = std::getenv("PDOG_SCRATCH_MB")) w.scratch_cap = (size_t)std::max(1, std::atoi(e)) << 20;
-    if (const char *e = std::getenv("PDOG_MAP_MB")) w.map_cap = (size_t)std::max(0, std::atoi(e)) << 20;
     if (const char *e = std::getenv("PDOG_FUSED_P")) {
         int a = 0, b = 0;
         if (std::sscanf(e, "%d,%d", &a, &b) == 2 && (a == 3 || a == 4 || a == 5 || a == 6 || a == 8) &&
             (b == 2 || b == 3 || b == 4 || b == 6 || b == 8)) { w.fused_pr = a; w.fused_pc = b; }
     }
-    if (const char *e = std::getenv("PDOG_HOST_THREADS")) w.host_threads = std::max(1, std::min(64, std::atoi(e)));
-    if (const char *e = std::getenv("PDOG_INGEST_CHUNK")) w.ingest_chunk = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("PDOG_LDS_PAD")) w.lds_pad = std::max(0, std::atoi(e));
+#endif
     return w;
 }
 
@@ -274,8 +282,6 @@ struct pdog_tracker {
     size_t tiled_lds = 0;
     int *d_tiled_ctl = nullptr;    // [cap][4]: current guess (2), partial arrivals, frame flag
     int tiled_ctl_cap = 0;
-    int *d_coop_cur = nullptr;     // [2] current guess of the cooperative single-clip chain, then 3 words of barrier state
-    int coop_grid = -1;            // workgroups of the cooperative chain kernel (0: not available for this tracker; -1: not determined yet)
     int chain_tmp_cap = 0;
     // two-pass path scratch
     f2 *d_V = nullptr;
@@ -298,6 +304,8 @@ struct pdog_tracker {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     f2 *d_taps_row = nullptr, *d_taps_col = nullptr;
     f2 *d_taps_roll = nullptr; // paired column-tap table of dog_roll.hpp
+    f2 *d_fold_r = nullptr;    // [n][n1 + l − 1] row-pass outputs of a folded remainder column (LaunchGeo::fold_r)
+    size_t fold_bytes = 0;
     float *d_part_val = nullptr, *d_part_sec = nullptr;
     unsigned long long *d_part_mask = nullptr;
     int *d_part_idx = nullptr;
@@ -344,7 +352,7 @@ fused_fn_t fused_kernel_for(int L, bool resp);
 // partly masked group of 13 outputs must stay inside the zero-padded row.  nout outputs, l taps.
 // `quantum` = outputs one round of a workgroup covers (groups × outputs per task); + l rounded up to a block of 16 taps + one block of prefetch
 int twopass_pitch_q(int nout, int L, int quantum) { return (round_up(nout, quantum) + L + 48) | 1; }
-int twopass_pitch(int nout, int L, int rows = HP_ROWS) { return twopass_pitch_q(nout, L, rows == 8 ? 32 * 7 : 16 * 13); } // the cooperative chain's fixed instances
+int twopass_pitch(int nout, int L, int rows = HP_ROWS) { return twopass_pitch_q(nout, L, rows == 8 ? 32 * 7 : 16 * 13); }
 
 // Outputs per task (P) of the two-pass ROW pass, per geometry.  A workgroup covers 16 × P outputs per round: a 257-wide
 // window on P = 13 (208 per round) ran a second round 24 % full.  Measured per launch (4096 windows, same session):
@@ -524,8 +532,8 @@ int launch_tiled(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
         if (t->tiled_ctl_cap < n) {
             if (t->d_tiled_ctl) (void)hipFree(t->d_tiled_ctl);
             t->d_tiled_ctl = nullptr; t->tiled_ctl_cap = 0;
-            HIP_TRY(hipMalloc(&t->d_tiled_ctl, sizeof(int) * 4 * (size_t)n));
-            HIP_TRY(hipMemset(t->d_tiled_ctl, 0, sizeof(int) * 4 * (size_t)n)); // the kernel leaves its counters at zero
+            HIP_TRY(hipMalloc(&t->d_tiled_ctl, sizeof(int) * (4 * (size_t)n + 1)));
+            HIP_TRY(hipMemset(t->d_tiled_ctl, 0, sizeof(int) * (4 * (size_t)n + 1))); // the kernel leaves its counters at zero; the last word is the abort word
             t->tiled_ctl_cap = n;
         }
     }
@@ -564,6 +572,8 @@ int launch_tiled(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     tg.dc_host = dc_host;
     tg.cur = t->d_tiled_ctl;
     tg.sync = reinterpret_cast<unsigned *>(t->d_tiled_ctl + 2 * (size_t)t->tiled_ctl_cap);
+    tg.abort = reinterpret_cast<unsigned *>(t->d_tiled_ctl + 4 * (size_t)t->tiled_ctl_cap);
+    tg.fault_inject = t->sw.fault_inject ? 1 : 0;
     const void *fn = d_out_resp ? (const void *)dog_tiled_kernel<true> : (const void *)dog_tiled_kernel<false>;
     const f2 *tr = t->d_taps_row, *tc = t->d_taps_col;
     if (chain_len > 1) {
@@ -763,7 +773,11 @@ int launch_finish(pdog_tracker *t, const LaunchGeo &g, int slot_w, int slot_last
     fg.out_ij = d_out_ij;
     fg.done_flag = d_done_flag;
     fg.done_value = done_value;
-    const size_t lds = t->exact ? refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_rows) : 0;
+    size_t lds = t->exact ? refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_rows) : 0;
+    if (g.fold_r) { // the folded remainder column's R values, one slice per wave (a window each)
+        lds = std::max(lds, (size_t)FINISH_WPB * (t->n1 + t->L - 1 + FOLD_GO) * sizeof(f2));
+        if (int rc = raise_lds_limit((const void *)dog_finish_kernel, lds)) return rc;
+    }
     hipLaunchKernelGGL(dog_finish_kernel, dim3((g.n + FINISH_WPB - 1) / FINISH_WPB), dim3(REFINE_NT), lds, t->stream, fg, (const f2 *)t->d_taps_row,
                        (const f2 *)t->d_taps_col);
     HIP_TRY(hipGetLastError());
@@ -840,6 +854,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     // frames of another size than the tracker's (the packed window tiles of pdog_detect_batch_host)
     const int FH = fh_override ? fh_override : t->fh, FW = fw_override ? fw_override : t->fw;
     LaunchGeo g;
+    g.fold_r = nullptr;
     g.frames = d_frames;
     g.frame_stride = frame_stride;
     g.row_stride = row_stride;
@@ -1014,12 +1029,34 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         }
     }
     const bool want_resp = g.resp != nullptr;
-    if (t->nthin) {
+    // A single remainder column (widths 64·k + 1: 257, 513, …) can be FOLDED into the last strip: its row pass rides in that
+    // strip (a ninth output in the last lane group), its R values go through d_fold_r to the finishing kernel, which runs the
+    // column's column pass — no second kernel re-reading a 65-column patch per window, no side stream.  The response-writing
+    // instances (parity checks, the response-map refinement) and the other kernel lengths keep dog_thin_kernel.
+    const int NA = t->n1 + t->L - 1;
+    const size_t fold_wave_lds = (size_t)(NA + FOLD_GO) * sizeof(f2);
+    // Measured (same-session A/B against dog_thin_kernel beside the strips): the folded strip is the slowest of its window (+6 %:
+    // 49 packed instructions per sub-chunk) and the finishing kernel gains the column pass — +2.7 % per cfg3 step (4 strips per
+    // window), −0.8 % per cfg4 step (8 strips).  A variant that kept the R column in the strip's LDS and ran the column pass in
+    // the strip's own wave cost a wave per SIMD (12.9 KB per wave) and +5 %.  So: folded from 8 strips per window on.
+    const bool fold = v.roll && roll_folds(v.LT) && t->nthin == 1 && !want_resp && !t->sw.no_fold && (t->nstrips >= 8 || t->sw.fold_always) &&
+                      (size_t)FINISH_WPB * fold_wave_lds <= kMaxLds - 1024;
+    if (fold) {
+        const size_t need = sizeof(f2) * (size_t)n * NA;
+        if (t->fold_bytes < need) {
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            if (t->d_fold_r) (void)hipFree(t->d_fold_r);
+            t->d_fold_r = nullptr; t->fold_bytes = 0;
+            HIP_TRY(hipMalloc(&t->d_fold_r, need));
+            t->fold_bytes = need;
+        }
+        g.fold_r = t->d_fold_r;
+    } else if (t->nthin) {
         // fork: the thin kernel only reads the frames and writes its own partial slots
         HIP_TRY(hipEventRecord(t->ev_fork, t->stream));
         HIP_TRY(hipStreamWaitEvent(t->aux_stream, t->ev_fork, 0));
         const size_t thin_lds = thin_lds_bytes(t->n1, t->L);
-        hipLaunchKernelGGL(want_resp ? v.thin_resp : v.thin, dim3(n * t->nthin), dim3(256), thin_lds, t->aux_stream, g,
+        hipLaunchKernelGGL(want_resp ? v.thin_resp : v.thin, dim3(round_up(n * t->nthin, 8)), dim3(256), thin_lds, t->aux_stream, g,
                            (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(t->ev_join, t->aux_stream));
@@ -1041,7 +1078,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     hipLaunchKernelGGL(fn, dim3(grid), dim3(v.NT), lds_bytes, t->stream, g,
                        (const f2 *)t->d_taps_row, (const f2 *)(v.roll ? t->d_taps_roll : t->d_taps_col));
     HIP_TRY(hipGetLastError());
-    if (t->nthin) HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0)); // join before the strip combine
+    if (t->nthin && !fold) HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0)); // join before the strip combine
     // roll: 64-column strips over the first `covered` columns, the last one shifted left to stay inside; ring: tw() columns each
     const int covered = t->nthin ? t->thin_x0 : t->n2;
     return launch_finish(t, g, v.tw(), v.roll ? std::max(0, covered - v.tw()) : (1 << 30), d_out_ij, nullptr, 0, v.roll, t->exact ? map : nullptr);
@@ -1247,7 +1284,7 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
             CREATE_TRY(hipMalloc(&t->d_rp, sizeof rp));
             CREATE_TRY(hipMemcpy(t->d_rp, &rp, sizeof rp, hipMemcpyHostToDevice));
         }
-        t->exact = !t->sw.no_exact && refine_lds_bytes(t->n1, t->L, 1, 8) <= kMaxLds - 8192;
+        t->exact = refine_lds_bytes(t->n1, t->L, 1, 8) <= kMaxLds - 8192;
         if (raise_lds_limit((const void *)dog_finish_kernel, refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_rows))) { pdog_destroy(t); return PDOG_E_HIP; }
     }
 #undef CREATE_TRY
@@ -1268,6 +1305,7 @@ int pdog_destroy(pdog_tracker *t)
     for (void *p : {(void *)t->d_part_val, (void *)t->d_part_idx, (void *)t->d_part_sec, (void *)t->d_part_mask, (void *)t->d_K64, (void *)t->d_g64, (void *)t->d_rp,
                     (void *)t->d_ref_stat})
         if (p) (void)hipFree(p);
+    if (t->d_fold_r) (void)hipFree(t->d_fold_r);
     if (t->d_frame) (void)hipFree(t->d_frame);
     if (t->d_small) (void)hipFree(t->d_small);
     if (t->h_pinned) (void)hipHostFree(t->h_pinned);
@@ -1278,7 +1316,6 @@ int pdog_destroy(pdog_tracker *t)
     if (t->d_dc) (void)hipFree(t->d_dc);
     if (t->d_counter) (void)hipFree(t->d_counter);
     if (t->d_chain_tmp) (void)hipFree(t->d_chain_tmp);
-    if (t->d_coop_cur) (void)hipFree(t->d_coop_cur);
     if (t->d_tiled_ctl) (void)hipFree(t->d_tiled_ctl);
     if (t->h2d_stream) { (void)hipStreamSynchronize(t->h2d_stream); (void)hipStreamDestroy(t->h2d_stream); }
     for (int k = 0; k < pdog_tracker::kIngestSlots; ++k) {
@@ -1371,21 +1408,29 @@ int pdog_set_variant(pdog_tracker *t, int variant)
     return choose_variant(t, variant);
 }
 
-int pdog_sync(pdog_tracker *t)
+// Drain the tracker's stream and report what its kernels raised while they ran: every entry point that waits for the
+// stream goes through here, so a fault surfaces at the first call that waits — not at a later, unrelated pdog_sync.
+static int drain_and_check(pdog_tracker *t, const char *who)
 {
-    if (!t) return fail(PDOG_E_ARG, "pdog_sync: null tracker");
+    HIP_TRY(hipSetDevice(t->device)); // (group mode: the current device is whichever rank was touched last)
     HIP_TRY(hipStreamSynchronize(t->stream));
     if (const int32_t raised = __atomic_load_n(&t->h_pinned[5], __ATOMIC_ACQUIRE)) { // raised by a kernel
         __atomic_store_n(&t->h_pinned[5], 0, __ATOMIC_RELEASE);
         if (raised == 2) { // a wait between resident workgroups gave up (wait_counter): the positions of that work are not valid
-            if (t->d_tiled_ctl) (void)hipMemset(t->d_tiled_ctl, 0, sizeof(int) * 4 * (size_t)t->tiled_ctl_cap);
-            return fail(PDOG_E_HIP, "pdog_sync: a kernel gave up waiting for its other workgroups (device-side watchdog); the results of the work just finished are not valid");
+            if (t->d_tiled_ctl) (void)hipMemset(t->d_tiled_ctl, 0, sizeof(int) * (4 * (size_t)t->tiled_ctl_cap + 1)); // counters, flags and the abort word
+            return fail(PDOG_E_HIP, std::string(who) + ": a kernel gave up waiting for its other workgroups (device-side watchdog); the results of the work just finished are not valid");
         }
         // a device-resident guess was out of range
-        return fail(PDOG_E_RANGE, "pdog_sync: a guess of the work just finished lies outside the padded frame (reference: BoundsError, "
+        return fail(PDOG_E_RANGE, std::string(who) + ": a guess of the work just finished lies outside the padded frame (reference: BoundsError, "
                                   "src/PawsomeTracker.jl:45-46); positions were computed with the fill value there");
     }
     return PDOG_OK;
+}
+
+int pdog_sync(pdog_tracker *t)
+{
+    if (!t) return fail(PDOG_E_ARG, "pdog_sync: null tracker");
+    return drain_and_check(t, "pdog_sync");
 }
 
 int pdog_set_exact(pdog_tracker *t, int on)
@@ -1399,11 +1444,31 @@ int pdog_set_exact(pdog_tracker *t, int on)
     return PDOG_OK;
 }
 
+int pdog_set_tuning(pdog_tracker *t, const char *key, int value)
+{
+    if (!t || !key) return fail(PDOG_E_ARG, "pdog_set_tuning: null pointer");
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    const std::string k(key);
+    const bool on = value != 0;
+    if (k == "host_copy") t->sw.host_copy = on;
+    else if (k == "host_sync") t->sw.host_sync = on;
+    else if (k == "twopass_4l") t->sw.twopass_4l = on;
+    else if (k == "no_roll_map") t->sw.no_roll_map = on;
+    else if (k == "no_fold") t->sw.no_fold = on;
+    else if (k == "fold_always") t->sw.fold_always = on;
+    else if (k == "fault_inject") t->sw.fault_inject = on;
+    else if (k == "no_tiled") {
+        t->sw.no_tiled = on;
+        if (int rc = setup_tiled(t)) return rc; // the tiled kernel's geometry is decided per tracker
+    } else return fail(PDOG_E_ARG, "pdog_set_tuning: unknown key '" + k + "'");
+    return PDOG_OK;
+}
+
 int pdog_get_exact_detail(pdog_tracker *t, uint64_t out[4])
 {
     if (!t || !out) return fail(PDOG_E_ARG, "pdog_get_exact_detail: null pointer");
-    HIP_TRY(hipSetDevice(t->device));
-    HIP_TRY(hipStreamSynchronize(t->stream));
+    if (int rc = drain_and_check(t, "pdog_get_exact_detail")) return rc;
     unsigned long long v[16];
     HIP_TRY(hipMemcpy(v, t->d_ref_stat, sizeof v, hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; ++i) out[i] = (uint64_t)v[i];
@@ -1420,8 +1485,7 @@ int pdog_get_exact(pdog_tracker *t, int *out_on, double *out_threshold, uint64_t
     if (out_on) *out_on = t->exact ? 1 : 0;
     if (out_threshold) *out_threshold = t->exact_all ? (double)__builtin_huge_valf() : (double)t->exact_T;
     if (out_refined) {
-        HIP_TRY(hipSetDevice(t->device));
-        HIP_TRY(hipStreamSynchronize(t->stream));
+        if (int rc = drain_and_check(t, "pdog_get_exact")) return rc;
         unsigned long long v = 0;
         HIP_TRY(hipMemcpy(&v, t->d_ref_stat, sizeof v, hipMemcpyDeviceToHost));
         *out_refined = (uint64_t)v;
@@ -1769,91 +1833,6 @@ extern "C" int pdog_detect_batch_host(pdog_tracker *t, const uint8_t *h_frames, 
 
 namespace {
 
-// One cooperative launch for a single clip whose window does not fit the fused kernel (dog_coop.hpp).  Returns
-// PDOG_OK with *launched = false when the path is not available (exact reasons: no cooperative-launch support, the
-// column-pass tile does not fit LDS, the runtime refused the launch) — the caller then falls back to stream-ordered launches.
-int launch_coop_chain(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride, int n_frames,
-                      const int32_t *d_start, int32_t *out_ij, int32_t *progress, bool *launched)
-{
-    *launched = false;
-    if (!t->small_twopass || t->coop_grid == 0 || !t->sw.coop) return PDOG_OK;
-    const int hr = COOP_HR;
-    const int NA = t->n1 + t->L - 1;
-    const int h1blocks = (NA + HP_ROWS - 1) / HP_ROWS, hblocks = (t->n2 + hr - 1) / hr;
-    const int pitchA = twopass_pitch(t->n2, t->L), pitchV = twopass_pitch(t->n1, t->L, hr);
-    const int NAc = NA;
-    // the refinement's scratch is this kernel's LDS: widest block that fits what the passes need anyway
-    const size_t l1 = (size_t)HP_ROWS * pitchA * sizeof(float), l2 = (size_t)hr * pitchV * sizeof(f2);
-    const size_t base = std::max({l1, l2, refine_lds_bytes(t->n1, t->L, 1, 8)});
-    int ref_cbw = 1, ref_rows = 8;
-    for (int cbw = std::min(t->n2, t->ref_cbw); cbw >= 1; --cbw) {
-        const size_t fixed_r = refine_lds_bytes(t->n1, t->L, cbw, 0);
-        if (fixed_r + (size_t)8 * refine_tile_pitch(cbw, t->L) > base) continue;
-        ref_cbw = cbw;
-        ref_rows = (int)std::min<size_t>((size_t)NAc, (base - fixed_r) / (size_t)refine_tile_pitch(cbw, t->L));
-        while (ref_rows > 8 && refine_lds_bytes(t->n1, t->L, cbw, ref_rows) > base) --ref_rows;
-        break;
-    }
-    if (base > kMaxLds - 1024) { t->coop_grid = 0; return PDOG_OK; }
-    if (t->coop_grid < 0) {
-        int coop = 0;
-        if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, t->device) != hipSuccess || !coop) { t->coop_grid = 0; return PDOG_OK; }
-        if (int rc = raise_lds_limit((const void *)dog_coop_chain_kernel, base)) return rc;
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)dog_coop_chain_kernel, 256, base) != hipSuccess || per_cu < 1 ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) != hipSuccess) { t->coop_grid = 0; return PDOG_OK; }
-        t->coop_grid = std::max(1, std::min(std::max(h1blocks, hblocks), per_cu * cus));
-    }
-    const size_t per_win = (size_t)t->n2 * NA * sizeof(f2);
-    if (t->v_bytes < per_win || t->cap_windows < 1 || !t->d_coop_cur) {
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        if (t->v_bytes < per_win) {
-            if (t->d_V) (void)hipFree(t->d_V);
-            t->d_V = nullptr; t->v_bytes = 0;
-            HIP_TRY(hipMalloc(&t->d_V, per_win));
-            t->v_bytes = per_win;
-        }
-        if (t->cap_windows < 1) { if (int rc = ensure_capacity(t, 1)) return rc; }
-        if (!t->d_coop_cur) HIP_TRY(hipMalloc(&t->d_coop_cur, sizeof(int) * 8));
-    }
-    CoopGeo cg;
-    std::memset(&cg, 0, sizeof cg);
-    LaunchGeo &g = cg.tg.g;
-    g.frames = d_frames;
-    g.frame_stride = frame_stride;
-    g.row_stride = row_stride;
-    g.part_val = t->d_part_val;
-    g.part_idx = t->d_part_idx;
-    g.part_sec = t->d_part_sec;
-    g.part_mask = t->d_part_mask;
-    g.ex = exact_ctl(t);
-    g.fh = t->fh; g.fw = t->fw; g.r1 = t->r1; g.r2 = t->r2; g.n1 = t->n1; g.n2 = t->n2;
-    g.L = t->L; g.fill = t->fill; g.nstrips = hblocks; g.nslots = hblocks; g.n = 1; g.nblocks = hblocks;
-    cg.tg.RT = t->d_V;
-    cg.tg.TWin = t->n2 + t->L - 1;
-    cg.tg.NA = NA;
-    cg.tg.h1blocks_per_win = h1blocks;
-    cg.tg.hblocks_per_win = hblocks;
-    cg.tg.pitchA = pitchA;
-    cg.tg.pitchV = pitchV;
-    cg.n_frames = n_frames;
-    cg.start = d_start;
-    cg.out_ij = out_ij;
-    cg.cur = t->d_coop_cur;
-    cg.rp = t->exact ? t->d_rp : nullptr;
-    cg.ref_cbw = ref_cbw;
-    cg.ref_rows = ref_rows;
-    cg.progress = progress;
-    cg.sync = reinterpret_cast<unsigned *>(t->d_coop_cur + 4);
-    HIP_TRY(hipMemsetAsync(t->d_coop_cur + 4, 0, sizeof(unsigned) * 4, t->stream));
-    const f2 *tr = t->d_taps_row, *tc = t->d_taps_col;
-    void *args[] = {(void *)&cg, (void *)&tr, (void *)&tc};
-    const hipError_t e = hipLaunchCooperativeKernel((const void *)dog_coop_chain_kernel, dim3(t->coop_grid), dim3(256), args, (unsigned)base, t->stream);
-    if (e != hipSuccess) { (void)hipGetLastError(); t->coop_grid = 0; return PDOG_OK; } // refused: stream-ordered launches instead
-    *launched = true;
-    return PDOG_OK;
-}
-
 // stream-ordered fallback: frame k's guess is frame k-1's (clamped) answer, read straight from the
 // output array — stream order is the dependency, no host round trip per frame
 int chain_by_launches(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride, int64_t row_stride,
@@ -1942,14 +1921,7 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
         if (launched) return PDOG_OK;
     }
     if (n_clips == 1) {
-        // one cooperative launch for the clip where it is available (windows beyond the fused kernel, any kernel the
-        // two-pass path serves) …
-        if (!t->forced_variant || t->var->twopass) {
-            bool launched = false;
-            if (int rc = launch_coop_chain(t, d_frames, frame_stride, row_stride, n_frames, d_start_guesses, d_out_ij, nullptr, &launched)) return rc;
-            if (launched) return PDOG_OK;
-        }
-        // … else stream order is the dependency: frame k's guess is read straight from frame k-1's answer
+        // stream order is the dependency: frame k's guess is read straight from frame k-1's answer
         return chain_by_launches(t, d_frames, frame_stride, row_stride, n_frames, d_start_guesses, d_out_ij);
     }
     if (t->chain_tmp_cap < n_clips) {
@@ -2024,11 +1996,6 @@ extern "C" int pdog_detect_chain_progress(pdog_tracker *t, const uint8_t *d_fram
         bool launched = false;
         if (int rc = launch_tiled(t, d_frames, frame_stride, row_stride, nullptr, t->d_small, 1, n_frames, d_out, nullptr, t->fh, t->fw, d_prog, 0, true,
                                   &launched)) return rc;
-        if (launched) return PDOG_OK;
-    }
-    if (!t->forced_variant || t->var->twopass) { // one cooperative launch: workgroup 0 publishes k + 1 after every frame
-        bool launched = false;
-        if (int rc = launch_coop_chain(t, d_frames, frame_stride, row_stride, n_frames, t->d_small, d_out, d_prog, &launched)) return rc;
         if (launched) return PDOG_OK;
     }
     for (int k = 0; k < n_frames; ++k) { // stream-ordered launches per frame; frame k's guess is read from the (host-mapped) answer k − 1

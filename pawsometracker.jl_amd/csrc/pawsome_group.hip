@@ -10,7 +10,9 @@
 // copy kernel on the root compacts them when n_total is not a multiple of the group size.
 #include "../../include/pawsome_dog.h"
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is opened when the first group is created (below)
+#include <dlfcn.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -28,10 +30,43 @@ int gfail(int code, const std::string &msg)
         hipError_t e__ = (expr);                                                                      \
         if (e__ != hipSuccess) return gfail(PDOG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
+// RCCL is opened lazily, by pdog_group_create: a C or Julia host that only uses the single-device ABI can load this
+// library on a machine (or loader path) without librccl, and no second RCCL copy enters a process that never asks for a
+// group.  dlopen by SONAME: a librccl the process already holds (PyTorch-ROCm's) is the one that is used.
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGather) Gather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) { r.error = std::string("librccl not found (") + (dlerror() ? dlerror() : "dlopen failed") + ")"; return; }
+        auto sym = [&](const char *n) { void *p = dlsym(r.handle, n); if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + n; return p; };
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.Gather = (decltype(r.Gather))sym("ncclGather");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    });
+    return r;
+}
 #define G_NCCL(expr)                                                                                  \
     do {                                                                                              \
         ncclResult_t r__ = (expr);                                                                    \
-        if (r__ != ncclSuccess) return gfail(PDOG_E_HIP, std::string(#expr) + ": " + ncclGetErrorString(r__)); \
+        if (r__ != ncclSuccess) return gfail(PDOG_E_HIP, std::string(#expr) + ": " + rccl().GetErrorString(r__)); \
     } while (0)
 
 // Contiguous shards whose sizes differ by at most one: the first n_total % ndev ranks own one window more.
@@ -103,7 +138,7 @@ int pdog_group_destroy(pdog_group *g)
     for (int r = 0; r < (int)g->tr.size(); ++r)
         if (g->tr[r]) (void)pdog_sync(g->tr[r]);
     for (int r = 0; r < (int)g->comm.size(); ++r)
-        if (g->comm[r]) (void)ncclCommDestroy(g->comm[r]);
+        if (g->comm[r]) (void)rccl().CommDestroy(g->comm[r]);
     for (int r = 0; r < (int)g->dev.size(); ++r) {
         (void)hipSetDevice(g->dev[r]);
         if (r < (int)g->d_local.size() && g->d_local[r]) (void)hipFree(g->d_local[r]);
@@ -124,6 +159,8 @@ int pdog_group_create(int ndev, const int *devices, int frame_h, int frame_w, do
     int have = 0;
     if (hipGetDeviceCount(&have) != hipSuccess || have <= 0)
         return gfail(PDOG_E_NODEV, "pdog_group_create: no HIP device (this library has no CPU path)");
+    if (!rccl().error.empty() || !rccl().handle)
+        return gfail(PDOG_E_NODEV, "pdog_group_create: RCCL is not available: " + rccl().error + " — the single-device entry points do not need it");
     pdog_group *g = new pdog_group();
     g->ndev = ndev;
     for (int r = 0; r < ndev; ++r) {
@@ -143,11 +180,11 @@ int pdog_group_create(int ndev, const int *devices, int frame_h, int frame_w, do
         if (rc) { pdog_group_destroy(g); return rc; } // pdog_last_error() already holds pdog_create's text
     }
     g->comm.assign(ndev, nullptr);
-    ncclResult_t nr = ncclCommInitAll(g->comm.data(), ndev, g->dev.data());
+    ncclResult_t nr = rccl().CommInitAll(g->comm.data(), ndev, g->dev.data());
     if (nr != ncclSuccess) {
         g->comm.clear();
         pdog_group_destroy(g);
-        return gfail(PDOG_E_HIP, std::string("pdog_group_create: ncclCommInitAll: ") + ncclGetErrorString(nr));
+        return gfail(PDOG_E_HIP, std::string("pdog_group_create: ncclCommInitAll: ") + rccl().GetErrorString(nr));
     }
     *out = g;
     return PDOG_OK;
@@ -172,6 +209,12 @@ int pdog_group_detect_batch(pdog_group *g, const uint8_t *const *d_frames, int64
     const int ndev = g->ndev;
     const int max_n = (n_total + ndev - 1) / ndev;
     const bool equal = n_total % ndev == 0;
+    for (int r = 0; r < ndev; ++r) { // every shard's pointers are checked BEFORE anything is launched on any rank
+        int lo, hi;
+        shard_bounds(n_total, ndev, r, lo, hi);
+        if (hi > lo && (!d_frames[r] || !d_guesses[r]))
+            return gfail(PDOG_E_ARG, "pdog_group_detect_batch: null frames / guesses pointer for rank " + std::to_string(r) + " (shard of " + std::to_string(hi - lo) + " windows)");
+    }
     // (re)size the per-rank result blocks and the root's gather buffer; every stream is drained first
     if (max_n > g->cap_local || (!equal && (long long)max_n * ndev > g->cap_gathered)) {
         for (int r = 0; r < ndev; ++r)
@@ -208,7 +251,6 @@ int pdog_group_detect_batch(pdog_group *g, const uint8_t *const *d_frames, int64
         if (int rc = pdog_get_stream(g->tr[r], &s)) return rc;
         st[r] = (hipStream_t)s;
         if (hi > lo) {
-            if (!d_frames[r] || !d_guesses[r]) return gfail(PDOG_E_ARG, "pdog_group_detect_batch: null shard pointer");
             int rc = pdog_detect_batch(g->tr[r], d_frames[r], frame_stride, row_stride, n_frames[r],
                                        d_frame_index ? d_frame_index[r] : nullptr, d_guesses[r], hi - lo, g->d_local[r], nullptr);
             if (rc) return rc;
@@ -216,15 +258,15 @@ int pdog_group_detect_batch(pdog_group *g, const uint8_t *const *d_frames, int64
     }
     // one gather of the (row, col) pairs to the root, each rank's part enqueued behind its own kernels
     int32_t *recv = equal ? d_out_ij : g->d_gathered;
-    G_NCCL(ncclGroupStart());
+    G_NCCL(rccl().GroupStart());
     for (int r = 0; r < ndev; ++r) {
-        ncclResult_t nr = ncclGather(g->d_local[r], recv, (size_t)2 * max_n, ncclInt32, 0, g->comm[r], st[r]);
+        ncclResult_t nr = rccl().Gather(g->d_local[r], recv, (size_t)2 * max_n, ncclInt32, 0, g->comm[r], st[r]);
         if (nr != ncclSuccess) {
-            (void)ncclGroupEnd();
-            return gfail(PDOG_E_HIP, std::string("pdog_group_detect_batch: ncclGather: ") + ncclGetErrorString(nr));
+            (void)rccl().GroupEnd();
+            return gfail(PDOG_E_HIP, std::string("pdog_group_detect_batch: ncclGather: ") + rccl().GetErrorString(nr));
         }
     }
-    G_NCCL(ncclGroupEnd());
+    G_NCCL(rccl().GroupEnd());
     if (!equal) {
         G_HIP(hipSetDevice(g->dev[0]));
         hipLaunchKernelGGL(group_compact_kernel, dim3((n_total + 255) / 256), dim3(256), 0, st[0], (const int32_t *)g->d_gathered, d_out_ij,
@@ -237,8 +279,26 @@ int pdog_group_detect_batch(pdog_group *g, const uint8_t *const *d_frames, int64
 int pdog_group_sync(pdog_group *g)
 {
     if (!g) return gfail(PDOG_E_ARG, "pdog_group_sync: null group");
-    for (int r = 0; r < g->ndev; ++r)
-        if (int rc = pdog_sync(g->tr[r])) return rc;
+    // EVERY rank is drained (and its raised flags cleared) whatever the others report; the first error is returned
+    int first = PDOG_OK;
+    std::string text;
+    for (int r = 0; r < g->ndev; ++r) {
+        const int rc = pdog_sync(g->tr[r]);
+        if (rc && !first) { first = rc; text = "rank " + std::to_string(r) + ": " + pdog_last_error(); }
+    }
+    return first ? gfail(first, text) : PDOG_OK;
+}
+
+// Test hook (tests/test_gpu_group.py): the copy kernel that compacts the gathered max-shard-sized blocks when the shards are
+// unequal — a path no one-GPU box reaches through pdog_group_detect_batch (with one rank the shards are always equal).
+// d_gathered: int32[ndev][max_n][2] with max_n = ⌈n_total / ndev⌉; d_out: int32[n_total][2]; both on the current device.
+int pdog_group_test_compact(const int32_t *d_gathered, int n_total, int ndev, int32_t *d_out)
+{
+    if (!d_gathered || !d_out || n_total <= 0 || ndev <= 0) return gfail(PDOG_E_ARG, "pdog_group_test_compact: bad argument");
+    const int max_n = (n_total + ndev - 1) / ndev;
+    hipLaunchKernelGGL(group_compact_kernel, dim3((n_total + 255) / 256), dim3(256), 0, 0, d_gathered, d_out, n_total, ndev, max_n);
+    G_HIP(hipGetLastError());
+    G_HIP(hipStreamSynchronize(0));
     return PDOG_OK;
 }
 

@@ -99,6 +99,10 @@ class Tracker:
         """Exact mode (default on): near-ties of the FP32 ranking are re-decided in the reference's Float64 arithmetic."""
         _lib.check(_lib.lib().pdog_set_exact(self._h, int(on)))   # 0 off, 1 on, 2 re-evaluate everything (self-check)
 
+    def set_tuning(self, key, value=1):
+        """Pin one of the library's alternative code paths (pdog_set_tuning): tests and A/B only."""
+        _lib.check(_lib.lib().pdog_set_tuning(self._h, key.encode(), int(value)))
+
     def exact_stats(self):
         """(on, threshold 2δ, windows re-evaluated so far) — pdog_get_exact."""
         on, thr, n = C.c_int(), C.c_double(), C.c_uint64()

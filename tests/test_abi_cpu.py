@@ -139,6 +139,17 @@ def test_c_abi_shard_partition_matches_the_python_one():
     assert L.pdog_shard_owner(10, 3, 10, C.byref(r), C.byref(k)) == _lib.PDOG_E_ARG
 
 
+def test_library_does_not_link_rccl():
+    """RCCL is opened by pdog_group_create (dlopen), not linked: a host that only uses the single-device ABI can load the
+    library where there is no librccl on the loader path."""
+    import subprocess
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-d", pt.LIB_PATH], capture_output=True, text=True)
+    if out.returncode != 0:
+        out = subprocess.run(["readelf", "-d", pt.LIB_PATH], capture_output=True, text=True)
+    needed = [l for l in out.stdout.splitlines() if "NEEDED" in l]
+    assert needed and not any("rccl" in l for l in needed), needed
+
+
 def test_group_create_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

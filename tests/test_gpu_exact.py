@@ -290,10 +290,11 @@ def test_hard_batches_large_windows_exact_and_not_slow(pt, oracle, monkeypatch):
         guesses = np.stack([rng.integers(150, 450, n), rng.integers(200, 600, n)], 1).astype(np.int32)
         d_f, d_fi, d_g = torch.from_numpy(frames).cuda(), torch.from_numpy(fi).cuda(), torch.from_numpy(guesses).cuda()
 
-        def run(exact):
+        def run(exact, no_map=False):
             bt = pt.BatchTracker(h, w, tw, ws, True, 128)
             bt.set_variant(100)                      # the roll kernel, as a large batch would run
             bt.set_exact(exact)
+            bt.set_tuning("no_roll_map", int(no_map))
             outs = []
             for _ in range(3):                       # the first batch recomputes its candidates, later ones use the map
                 outs.append(bt.detect(d_f, d_g, d_fi).cpu().numpy())
@@ -310,9 +311,7 @@ def test_hard_batches_large_windows_exact_and_not_slow(pt, oracle, monkeypatch):
 
         got, dt, refined = run(True)
         raw, dt_raw, _ = run(False)
-        monkeypatch.setenv("PDOG_NO_ROLL_MAP", "1")
-        got_nomap, _, _ = run(True)
-        monkeypatch.delenv("PDOG_NO_ROLL_MAP")
+        got_nomap, _, _ = run(True, no_map=True)
         assert refined >= 5 * n                                          # every window of every batch was flagged
         assert np.array_equal(got, got_nomap)
         for b in range(0, n, 16):                                        # 16 windows against the reference's own arithmetic

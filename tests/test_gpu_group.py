@@ -57,6 +57,51 @@ def test_group_of_one_equals_detect_batch(pt, oracle):
         assert np.array_equal(want[:8], ref)
 
 
+def test_unequal_shard_compaction_kernel(pt):
+    """pdog_group_detect_batch gathers max-shard-sized blocks and, when n_total is not a multiple of the group size, compacts
+    them on the root with a copy kernel.  With one rank the shards are always equal, so that kernel is driven directly
+    here (pdog_group_test_compact) on synthetic gathered buffers of 2 … 8 ranks and checked against pdog_shard_owner /
+    pdog_shard_range — the partition the multi-GPU path is built on."""
+    import ctypes as C
+    import torch
+    L = pt.lib()
+    for ndev, n_total in ((3, 10), (3, 11), (8, 8191), (8, 8193), (2, 1), (5, 3), (7, 4096), (4, 4098)):
+        max_n = (n_total + ndev - 1) // ndev
+        gathered = np.full((ndev, max_n, 2), -7, np.int32)            # padding entries must never reach the output
+        want = np.empty((n_total, 2), np.int32)
+        for w in range(n_total):
+            r, k = C.c_int(), C.c_int()
+            assert L.pdog_shard_owner(n_total, ndev, w, C.byref(r), C.byref(k)) == 0
+            lo, hi = C.c_int(), C.c_int()
+            assert L.pdog_shard_range(n_total, ndev, r.value, C.byref(lo), C.byref(hi)) == 0 and lo.value + k.value == w < hi.value
+            gathered[r.value, k.value] = (w + 1, 3 * w + 2)
+            want[w] = (w + 1, 3 * w + 2)
+        d_g = torch.from_numpy(gathered).cuda()
+        d_o = torch.full((n_total, 2), -1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        pt._lib.check(L.pdog_group_test_compact(C.c_void_p(d_g.data_ptr()), n_total, ndev, C.c_void_p(d_o.data_ptr())))
+        assert np.array_equal(d_o.cpu().numpy(), want), (ndev, n_total)
+
+
+def test_group_checks_every_shard_pointer_before_launching(pt):
+    """A null frames / guesses pointer for any rank with a non-empty shard is PDOG_E_ARG before anything is launched."""
+    import ctypes as C
+    import torch
+    gt = pt.GroupTracker([0], 120, 160, 25, (45, 45), True, 128)
+    L = pt.lib()
+    out = torch.zeros((4, 2), dtype=torch.int32, device="cuda")
+    frames = torch.zeros((4, 120, 160), dtype=torch.uint8, device="cuda")
+    guesses = torch.full((4, 2), 60, dtype=torch.int32, device="cuda")
+    ptrs = lambda t: (C.c_void_p * 1)(C.c_void_p(t.data_ptr()) if t is not None else None)
+    nf = (C.c_int * 1)(4)
+    for fr, gu in ((None, guesses), (frames, None)):
+        rc = L.pdog_group_detect_batch(gt._h, ptrs(fr), 120 * 160, 160, nf, None, ptrs(gu), 4, C.c_void_p(out.data_ptr()))
+        assert rc == pt._lib.PDOG_E_ARG and b"rank 0" in L.pdog_last_error()
+    gt.sync()
+    assert int(out.abs().sum()) == 0             # nothing ran
+    gt.close()
+
+
 def test_group_rejects_bad_devices(pt):
     import torch
     nd = torch.cuda.device_count()
@@ -184,67 +229,25 @@ def test_device_guess_out_of_range_is_reported_by_sync(pt, oracle):
         bt.close()
 
 
-def test_switches_are_read_once_at_create(pt, oracle, monkeypatch):
-    """The PDOG_* environment switches are sampled when a tracker is created, never on the launch path: flipping one
-    afterwards does not change a live tracker, a new tracker sees it."""
+def test_no_path_switch_comes_from_the_environment(pt, oracle, monkeypatch):
+    """The product library reads resource limits from the environment and nothing else: the switches that used to select
+    code paths (round 2: PDOG_NO_EXACT silently removed the position guarantee for every tracker of the process) do
+    nothing; the same paths are pinned per tracker, explicitly, through pdog_set_exact / pdog_set_tuning."""
     from oracle import synth
     frames, guesses, _ = synth.make_batch(1, 120, 160, 25, (22, 22), True, seed=4, noise=2)
-    monkeypatch.delenv("PDOG_NO_EXACT", raising=False)
+    for name in ("PDOG_NO_EXACT", "PDOG_HOST_COPY", "PDOG_NO_TILED", "PDOG_TWOPASS_4L"):
+        monkeypatch.setenv(name, "1")
     t1 = pt.Tracker(frames[0], 25, (45, 45), True)
     assert t1.exact_stats()[0] is True
-    monkeypatch.setenv("PDOG_NO_EXACT", "1")
-    assert t1.exact_stats()[0] is True
-    t2 = pt.Tracker(frames[0], 25, (45, 45), True)
-    assert t2.exact_stats()[0] is False
     g = (int(guesses[0, 0]), int(guesses[0, 1]))
-    assert t1(g) == t2(g)
-    t1.close(); t2.close()
+    want = t1(g)
+    t1.set_exact(0)
+    assert t1.exact_stats()[0] is False and t1(g) == want
+    for key in ("host_copy", "host_sync", "twopass_4l", "no_tiled", "no_roll_map", "no_fold", "fold_always"):
+        t1.set_tuning(key, 1)
+        assert t1(g) == want, key
+        t1.set_tuning(key, 0)
+    with pytest.raises(pt.PdogError):
+        t1.set_tuning("no_such_key", 1)
+    t1.close()
 
-
-@pytest.mark.skipif(not os.environ.get("PDOG_TEST_COOP"), reason="the cooperative chain is opt-in (slower than the default path) and waits on "
-                    "device-side barriers: run it on purpose with PDOG_TEST_COOP=1, not in the unattended suite")
-def test_cooperative_single_clip_chain(pt, oracle, monkeypatch):
-    """A single clip whose window does not fit the fused kernel as ONE cooperative launch (csrc/dog_coop.hpp: resident
-    workgroups, grid barriers between row pass, column pass and the finishing step; opt-in with PDOG_COOP=1 because it
-    measured slower than the launches it replaces) — positions equal to the oracle's serial chain
-    (src/PawsomeTracker.jl:163-169, :167) and to the default stream-ordered launches, with the refinement forced on every
-    frame too, and through the progress-publishing form."""
-    import torch
-    from oracle import synth
-    from oracle.dog_oracle import OracleTracker
-    for tw, ws, fh, fw, nf in ((25, (256, 256), 400, 520, 10), (120, (205, 205), 420, 500, 4), (41, (130, 190), 300, 400, 6)):
-        radii = (ws[0] // 2, ws[1] // 2)
-        rng = np.random.default_rng(int(tw))
-        centres = np.cumsum(rng.integers(-6, 7, (nf, 2)), 0) + np.array([fh // 2, fw // 2])
-        clip = np.stack([synth.disc_frame(fh, fw, (int(c[0]), int(c[1])), tw, True) for c in centres])
-        clip = np.clip(clip.astype(np.int16) + rng.integers(-3, 4, clip.shape), 0, 255).astype(np.uint8)
-        start = (int(centres[0, 0]) + 5, int(centres[0, 1]) - 7)
-        ot = OracleTracker(clip[0], tw, ws, True, oracle)
-        want, g = [], start
-        for k in range(nf):
-            ot.data[...] = clip[k]
-            g = ot(g)
-            want.append(list(g))
-        d_clip = torch.from_numpy(clip).cuda()
-        monkeypatch.setenv("PDOG_COOP", "1")
-        monkeypatch.setenv("PDOG_NO_TILED", "1")     # (the default for such a clip is the tiled kernel, tests/test_gpu_tiled.py)
-        for exact in (1, 2):
-            if exact == 2 and tw == 120:
-                continue                         # every pixel through the dense chain at l = 293: minutes
-            bt = pt.BatchTracker(fh, fw, tw, ws, True, ot.fill)
-            bt.set_exact(exact)
-            assert bt.kernel_for_batch(1) == 200          # too large for the fused kernel: the two-pass family
-            got = bt.detect_chain(d_clip, start)
-            bt.sync()
-            assert got.cpu().numpy().tolist() == want, (tw, exact)
-            cp = bt.detect_chain_progress(d_clip, start)
-            assert cp.wait().tolist() == want and cp.done() == nf
-            cp.close()
-            bt.close()
-        monkeypatch.delenv("PDOG_COOP")
-        monkeypatch.delenv("PDOG_NO_TILED")
-        bt = pt.BatchTracker(fh, fw, tw, ws, True, ot.fill)
-        got = bt.detect_chain(d_clip, start)
-        bt.sync()
-        assert got.cpu().numpy().tolist() == want, (tw, "launches")
-        bt.close()

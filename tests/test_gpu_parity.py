@@ -70,12 +70,12 @@ def test_every_l65_variant(pt, golden, variant):
     assert n_run >= 3
 
 
-def test_golden_via_the_copying_host_path(pt, golden, monkeypatch):
+def test_golden_via_the_copying_host_path(pt, golden):
     """The functor's fallback for windows that do not fit the fused kernel (tile uploaded with copy commands, batch
     kernels) on the golden cases that normally take the in-place path."""
-    monkeypatch.setenv("PDOG_HOST_COPY", "1")
     for c in golden:
         t = pt.Tracker(c["frame"], c["tw"], c["ws"], c["darker"])
+        t.set_tuning("host_copy", 1)
         assert t(c["guess"]) == c["ij"], c["name"]
         t.close()
 
@@ -392,16 +392,13 @@ def test_two_pass_scratch_chunking(pt, oracle, monkeypatch):
     monkeypatch.delenv("PDOG_SCRATCH_MB")
     assert np.array_equal(_batch(pt, frames, guesses, tw, ws, True, fill), ref)
     # up to 16 windows the two-pass path runs as two launches (DC level inside the row pass, strip combine by the last
-    # column-pass workgroup); PDOG_TWOPASS_4L forces the four-launch form on the same windows.  Twice per tracker:
+    # column-pass workgroup); pdog_set_tuning("twopass_4l") forces the four-launch form on the same windows.  Twice per tracker:
     # the per-window counters must be back at zero after a launch.
     import torch
     for n in (1, 5, 16, 17):
         for four in (False, True):
-            if four:
-                monkeypatch.setenv("PDOG_TWOPASS_4L", "1")
-            else:
-                monkeypatch.delenv("PDOG_TWOPASS_4L", raising=False)
             bt = pt.BatchTracker(160, 200, tw, ws, True, fill)
+            bt.set_tuning("twopass_4l", int(four))
             d_f, d_g = torch.from_numpy(frames[:n]).cuda(), torch.from_numpy(guesses[:n]).cuda()
             for _ in range(2):
                 got, resp = bt.detect(d_f, d_g, want_resp=True)

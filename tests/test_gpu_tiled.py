@@ -73,9 +73,9 @@ def test_functor_and_small_batches_vs_dense_oracle(pt, oracle, ws):
     bt.close()
 
 
-def test_chain_equals_oracle_chain_and_two_pass_launches(pt, oracle, monkeypatch):
+def test_chain_equals_oracle_chain_and_two_pass_launches(pt, oracle):
     """ij[k] = trckr(ij[k-1]) (:167) over a clip: one cooperative launch of the tiled kernel, positions equal to the
-    oracle's serial chain, to the same library with PDOG_NO_TILED=1 (stream-ordered two-pass launches), and to the
+    oracle's serial chain, to the same library with the tiled kernel pinned off (stream-ordered two-pass launches), and to the
     progress variant that publishes every frame."""
     import torch
     tw, ws, h, w, n = 25, (257, 257), 540, 720, 40
@@ -89,8 +89,9 @@ def test_chain_equals_oracle_chain_and_two_pass_launches(pt, oracle, monkeypatch
         want.append(g)
     d_f = torch.from_numpy(frames).cuda()
 
-    def chain():
+    def chain(no_tiled=False):
         bt = pt.BatchTracker(h, w, tw, ws, True, FILL)
+        bt.set_tuning("no_tiled", int(no_tiled))
         out = bt.detect_chain(d_f, (h // 2, w // 2))
         bt.sync()
         res = [tuple(r) for r in out.cpu().numpy().tolist()]
@@ -103,8 +104,7 @@ def test_chain_equals_oracle_chain_and_two_pass_launches(pt, oracle, monkeypatch
 
     res, prog, tiled = chain()
     assert tiled and res == want and prog == want
-    monkeypatch.setenv("PDOG_NO_TILED", "1")
-    res2, prog2, tiled2 = chain()
+    res2, prog2, tiled2 = chain(no_tiled=True)
     assert not tiled2 and res2 == want and prog2 == want
 
 
@@ -224,3 +224,41 @@ def test_few_clips_share_one_cooperative_launch(pt, oracle):
         for c in range(n_clips):
             assert [tuple(r) for r in got[c].tolist()] == want[c], (n_clips, c)
         bt.close()
+
+
+def test_device_side_wait_gives_up_promptly_and_recovers(pt, oracle):
+    """The tiled kernel's workgroups wait for each other between the frames of a clip (wait_counter, dog_kernels.hpp).  A peer
+    that never arrives must not hang the GPU: the wait is bounded by wall time (≈1 s of s_memrealtime), the first wave to give
+    up raises an abort word every other wait polls — so the whole launch ends about one timeout after the stall, not one
+    timeout per waiting workgroup and frame — nothing is published after the fault, pdog_sync reports PDOG_E_HIP once and
+    zeroes the control words, and the same tracker then walks the same clip correctly.  The stall is injected
+    (pdog_set_tuning "fault_inject": sub-window 0 never delivers the partial of its second frame)."""
+    import time
+    import torch
+    tw, ws, h, w, n = 25, (257, 257), 540, 720, 6
+    frames, _ = _clip(n, h, w, seed=21)
+    K = oracle.dog_kernel(oracle.sigma(tw), True)
+    radii = (ws[0] // 2, ws[1] // 2)
+    want, g = [], (h // 2, w // 2)
+    for k in range(n):
+        g = oracle.detect(frames[k], FILL, K, radii, g)
+        want.append(g)
+    d_f = torch.from_numpy(frames).cuda()
+    bt = pt.BatchTracker(h, w, tw, ws, True, FILL)
+    assert bt.kernel_for_batch(1) == 400
+    bt.set_tuning("fault_inject", 1)
+    t0 = time.perf_counter()
+    cp = bt.detect_chain_progress(d_f, (h // 2, w // 2))
+    with pytest.raises(pt.PdogError) as e:
+        bt.sync()
+    dt = time.perf_counter() - t0
+    assert e.value.code == pt._lib.PDOG_E_HIP and "watchdog" in str(e.value)
+    assert dt < 4.0, dt                      # one timeout (≈1 s), not one per workgroup and frame
+    assert cp.done() <= 1                    # frame 0 finished before the stall; nothing was published after it
+    cp.close()
+    bt.sync()                                # reported once
+    bt.set_tuning("fault_inject", 0)
+    out = bt.detect_chain(d_f, (h // 2, w // 2))
+    bt.sync()
+    assert [tuple(r) for r in out.cpu().numpy().tolist()] == want
+    bt.close()
