@@ -214,7 +214,7 @@ def tracking_sanity(np, got, centres, guesses_h, fh, fw, tw, radii, noise):
         assert err <= (1 if noise else 0), f"tracking sanity failed: max |pos - centre| = {err}"
 
 
-def result_line(args, desc, world, dt, kern_ms, batch, info, kernel_for_batch, fh, fw, tw, sharding):
+def result_line(args, desc, world, dt, kern_ms, batch, info, kernel_for_batch, fh, fw, tw, sharding, traffic_key=None):
     n_total = batch * world
     value = n_total * args.steps / dt
     abytes = int(info.algorithmic_bytes_per_window)
@@ -231,7 +231,7 @@ def result_line(args, desc, world, dt, kern_ms, batch, info, kernel_for_batch, f
                    "noise_levels": args.noise, "variant": info.variant, "kernel_for_this_batch": kernel_for_batch,
                    "strips": info.n_strips, "sharding": sharding},
         "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach_gbs / HBM_PEAK_GBS, "traffic": stored_traffic(args.workload, info.variant, batch),
+                     "frac": ach_gbs / HBM_PEAK_GBS, "traffic": stored_traffic(traffic_key or args.workload, info.variant, batch),
                      "kernel_ms": kern_ms, "algorithmic_bytes_per_window": abytes,
                      # what `frac` would be with the FP32 vector ALUs 100 % busy on algorithmic FMAs: the ceiling of this path
                      "frac_at_fp32_vector_peak": abytes / (afma / VALU_PEAK_FMA) / 1e9 / HBM_PEAK_GBS,
@@ -372,7 +372,7 @@ def run_chain(args):
     if not os.environ.get("PDOG_BENCH_NOCHECK"):
         assert err <= (1 if args.noise else 0), f"chain lost the target: max |pos - centre| = {err}"
     res = result_line(args, desc + f" [--chain: one clip of {n_frames} frames walked serially]", 1, dt, kern_ms, n_frames, info, "chain", fh, fw, tw,
-                      "single GPU, one clip (a serial chain does not shard: replicas only)")
+                      "single GPU, one clip (a serial chain does not shard: replicas only)", traffic_key=args.workload + "_chain")
     res["config"]["chain"] = True
     res["roofline"]["note"] = ("serial chain: one workgroup walks the clip, so this line is LATENCY (us per frame = ms_per_step * 1000 / frames), "
                                "not throughput; achieved/valu are the clip's algorithmic bytes and FMAs over the clip's time. " + res["roofline"]["note"])
