@@ -158,7 +158,10 @@ struct RefineCtx {
     k64_ptr g64;         // [2][l]: the normalised Gaussians σ and √2σ in Float64
     double dir;          // direction, :42
     double T64;          // 2δ64
-    float T;             // 2δ for |pixel − dc| ≤ 255
+    float T;             // 2δ for |pixel − dc| ≤ 255: the main kernel's own values against its own maximum (the flag, the response map)
+    float T_rescan = 0.f; // δ_main + δ_plain: values RECOMPUTED here with plain chains against the main kernel's maximum; 0 = T (main kernel
+                          // with plain chains too).  The two-pass kernels accumulate in blocks (dog_twopass.hpp): their δ is ≈13× smaller
+    int vmax_known = -1;  // ≥ 0: the window's own V = max |pixel − dc| (the two-pass row pass collects it): thresholds scale with V/255 from the start
     float second;        // the window's FP32 runner-up value and the FP32 argmax (column-major index): with the window's own
     int fp32_idx;        // |pixel − dc| bound the flag may turn out unnecessary (fp32_idx < 0: not supplied, never withdrawn)
     int v_after = 64;    // map path: candidates of the first scan beyond which the window's own V is worth its pass over the tile
@@ -219,8 +222,16 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
     // Taken up front where the candidates have to be recomputed (no response map); with a map only when the first scan
     // finds more than a few dozen candidates — on a long kernel's tile the pass costs as much as it saves otherwise (cfg5:
     // 247 KB per window, 36 candidates).
-    float thr = M - c.T;
+    const float T_r = c.T_rescan > 0.f ? c.T_rescan : c.T;
+    float thr = M - c.T, thr_r = M - T_r; // thr: values of the main kernel (partials, response map); thr_r: values recomputed here
     bool have_v = false;
+    if (c.vmax_known >= 0 && c.T < __builtin_huge_valf()) { // the window's own V is known: δ is proportional to it
+        if (c.vmax_known == 0 && c.fp32_idx >= 0) return c.fp32_idx; // flat tile: every response exactly equal in both arithmetics
+        const float sc = (float)c.vmax_known * (1.0f / 255.0f) * 1.00001f;
+        thr = M - c.T * sc;
+        thr_r = M - T_r * sc;
+        have_v = true;
+    }
     auto tighten = [&]() -> bool { // true: the flag is withdrawn, the FP32 argmax stands
         float T_eff = c.T;
         have_v = true;
@@ -272,6 +283,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
         __syncthreads();
         if (c.T < __builtin_huge_valf()) T_eff = c.T * ((float)vmax * (1.0f / 255.0f)) * 1.00001f; // (pdog_set_exact(t, 2): T = ∞ stays)
         thr = M - T_eff;
+        thr_r = c.T < __builtin_huge_valf() ? M - T_r * ((float)vmax * (1.0f / 255.0f)) * 1.00001f : thr;
         // flat tile (every pixel = dc: all responses exactly equal in both arithmetics) or a runner-up further than the
         // window's own T below the maximum: the FP32 argmax is the reference's
         if (c.fp32_idx >= 0 && c.T < __builtin_huge_valf() && (vmax == 0 || M - c.second > T_eff)) {
@@ -296,7 +308,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
     // no map, many blocks to recompute (a hard window: noise only, a faint target): the window's own V first, and the list
     // again under the tighter threshold — a window with one or two blocks listed (cfg4's one flagged window in 1 024) is
     // recomputed sooner than its 333 KB tile is scanned
-    if (!map && cnt[4] > 4) {
+    if (!map && cnt[4] > 4 && !have_v) {
         __syncthreads();
         if (tighten()) return c.fp32_idx;
         if (tid == 0) cnt[4] = 0;
@@ -337,7 +349,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
     };
     if (use_map) {
         scan_map();
-        if (cnt[1] || cnt[0] > c.v_after) { // many pixels within the V = 255 threshold: the window's own V, then once more
+        if ((cnt[1] || cnt[0] > c.v_after) && !have_v) { // many pixels within the V = 255 threshold: the window's own V, then once more
             __syncthreads();
             if (tighten()) return c.fp32_idx;
             if (tid == 0) { cnt[0] = 0; cnt[1] = 0; mm[0] = 0x7fffffff; mm[1] = -1; }
@@ -475,7 +487,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
                     acc = __builtin_fmaf(r.x, w.x, acc);
                     acc = __builtin_fmaf(r.y, w.y, acc);
                 }
-                if (acc >= thr) {
+                if (acc >= thr_r) {
                     const int lin = (x0 + x) * g.n1 + y;
                     if (direct) {
                         const double F = full ? exact_patch((const uint8_t *)(tile + y * tp + x), (long long)tp, L, c.K, lut)
@@ -762,6 +774,8 @@ struct FinishGeo {
     int use_mask;                // the main slots carry per-column masks (roll kernel, slot_w = 64)
     int v_after;                 // RefineCtx::v_after
     const float *map;            // null, or the batch's FP32 responses [n][n2][n1] (two-pass path): refine_window reads the candidates off it
+    const int *vmax;             // null, or [n]: each window's own V = max |pixel − dc| (two-pass row pass): the flag and the refinement scale T with V/255
+    float T_rescan;              // RefineCtx::T_rescan (0: same as g.ex.T)
     int32_t *out_ij;             // [n][2]
     int32_t *done_flag;          // NULL or host-coherent ticket word (see dog_fused.hpp): published with window 0's final answer
     int32_t done_value;
@@ -814,7 +828,8 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
             peak_wave_reduce(pk);
             if (lane == 0) {
                 const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
-                rf = fg.K64 && (pk.best - pk.second <= g.ex.T);
+                const float Tb = (fg.vmax && g.ex.T < __builtin_huge_valf()) ? g.ex.T * ((float)fg.vmax[b] * (1.0f / 255.0f)) * 1.00001f : g.ex.T;
+                rf = fg.K64 && (pk.best - pk.second <= Tb);
                 best = pk.best;
                 sec = pk.second;
                 bidx = pk.idx;
@@ -859,6 +874,8 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
         c.second = s_sec2[w];
         c.fp32_idx = s_idx2[w];
         c.v_after = fg.v_after;
+        c.T_rescan = fg.T_rescan;
+        c.vmax_known = fg.vmax ? fg.vmax[b] : -1;
         c.cbw = fg.cbw;
         c.tile_rows = fg.tile_rows;
         c.lds = smem;

@@ -332,12 +332,14 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
     constexpr bool FOLD_EXTRA = (8 * SB < TW + L);
     const bool fold = FOLD_OK && g.fold_r != nullptr && s == g.nstrips - 1; // wave-uniform
     const int xcol = tj0 + 8 * SB;                                          // frame col of the extra byte
+    // (unconditional load at an address clamped into the frame, validity applied when the byte is used: a load inside a branch
+    // is waited for where the branch ends — a full memory latency per sub-chunk in the folding waves)
+    const int xcol_c = min(max(xcol, 0), g.fw - 1);
     auto load_extra = [&](int a_row) -> uint32_t {
-        const int gi = ti0 + a_row;
-        uint32_t v = (uint32_t)g.fill;
-        if (sseg == SEGS - 1 && a_row < NA && gi >= 0 && gi < g.fh && xcol >= 0 && xcol < g.fw) v = frame[(long long)gi * g.row_stride + xcol];
-        return v;
+        const int gi = min(max(ti0 + a_row, 0), g.fh - 1);
+        return frame[(long long)gi * g.row_stride + xcol_c];
     };
+    auto extra_ok = [&](int a_row) { const int gi = ti0 + a_row; return a_row < NA && gi >= 0 && gi < g.fh && xcol >= 0 && xcol < g.fw; };
 
     f2 acc2[S / 2];
 #pragma unroll
@@ -350,11 +352,14 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
 
     unsigned long long stamp_c0 = 0, stamp_r0 = 0;
     if (ABL & 16) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
+    // (Tried: a fast staging path for strips wholly inside the frame — one running pointer per lane instead of load16's row
+    // tests, fill pre-load and 64-bit row multiply, ≈10 VALU instructions fewer per sub-chunk: 0.4–0.6 % SLOWER in a three-way
+    // same-session comparison.  The kernel does not feel a handful of VALU instructions beside its 900 packed ones.)
+    const int nsub = (NA + CH - 1) / CH;
     uint32_t pre[SB / 4];
     load16(srow, pre);
     uint32_t pre_x = 0;
     if (FOLD_EXTRA && fold) pre_x = load_extra(srow);
-    const int nsub = (NA + CH - 1) / CH;
     const int rr = lane & 7, rgx = lane >> 3; // row-pass task: row rr, output group rgx
     const long long resp_base = (long long)b * g.n1 * g.n2;
 
@@ -370,11 +375,12 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
                 const f2 v23 = f2{(float)((word >> 16) & 0xffu), (float)(word >> 24)} + ndc;
                 *reinterpret_cast<f4 *>(dst + 4 * q) = f4{v01.x, v01.y, v23.x, v23.y};
             }
-            if (FOLD_EXTRA && fold) {
-                if (sseg == SEGS - 1) A[roll_row_base(srow, L) + 8 * SB] = (float)pre_x - (float)dc;
-                pre_x = load_extra((sc + 1) * CH + srow);
+            if (FOLD_EXTRA && fold && sseg == SEGS - 1)
+                A[roll_row_base(srow, L) + 8 * SB] = (float)(extra_ok(sc * CH + srow) ? (int)pre_x : g.fill) - (float)dc;
+            if (!(ABL & 8)) {
+                load16((sc + 1) * CH + srow, pre);
+                if (FOLD_EXTRA && fold) pre_x = load_extra((sc + 1) * CH + srow);
             }
-            if (!(ABL & 8)) load16((sc + 1) * CH + srow, pre);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier(); // the LDS traffic is wave-private: the fences' waits are all the ordering needed

@@ -41,9 +41,19 @@ struct TwoPassGeo {
     int32_t *__restrict__ out_ij; // [n][2] final positions, written by the last column-pass workgroup of a window
     int32_t *done_flag;          // NULL, or a word in host-coherent memory that receives done_value (system-scope release)
     int32_t done_value;          // right after window 0's answer: the host functor polls it (see dog_fused.hpp)
+    int *__restrict__ vmax;      // NULL, or [n]: the window's own V = max |pixel − dc| over its padded tile, collected by the row pass
+                                 // (exact mode's error bound is proportional to it: the finishing kernel flags with the window's V, not 255)
 };
 
-static __global__ __launch_bounds__(64) void dog_dc_kernel(const LaunchGeo g, int *__restrict__ dc)
+// BLOCKED ACCUMULATION (both passes).  Each pass adds its l (or l÷2 + 1 paired) terms in chains of one TRIP of the register ring
+// (NB·U taps: 16–24) and adds the chains' sums up, instead of one chain of up to 293 FMAs: the rounding-error bound of a chain of
+// n FMAs is ≈n·u·Σ|terms|, that of B chains of m plus B additions ≈(m + B)·u·Σ|terms| — 7× tighter at l = 293.  With the one-chain
+// bound δ(l = 293) = 1.05e-4 exceeded the distance between NEIGHBOURING responses at σ = 51 (≈2e-5): exact mode flagged and
+// re-decided every cfg5 window.  Cost: one v_pk_add_f32 + one v_mov_b64 per output and trip (≈+4 % instructions).
+// Every output still sees the same operations in the same order: equal inputs give bit-equal outputs, flat windows tie exactly.
+__host__ __device__ constexpr int twopass_ring(int P, int U) { return ((P + 2 * U - 1 + U - 1) / U) * U; } // register-ring slots = taps per trip
+
+static __global__ __launch_bounds__(64) void dog_dc_kernel(const LaunchGeo g, int *__restrict__ dc, int *__restrict__ vmax)
 {
     const int b = blockIdx.x, lane = threadIdx.x, hw = g.L >> 1;
     const int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
@@ -52,7 +62,10 @@ static __global__ __launch_bounds__(64) void dog_dc_kernel(const LaunchGeo g, in
     int sum = dc_sample_sum(g, frame, g1 - g.r1 - 1 - hw, g2 - g.r2 - 1 - hw, g.L, lane, 64);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    if (lane == 0) dc[b] = dc_from_sum(sum, g.fill);
+    if (lane == 0) {
+        dc[b] = dc_from_sum(sum, g.fill);
+        if (vmax) vmax[b] = 0; // collected by the row pass that follows
+    }
 }
 
 // ---- row pass (u8 rows → RT) ----
@@ -95,6 +108,7 @@ __device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restr
     // into the frame row (a clamped dword still holds every in-frame byte its group needs, at a shifted position);
     // the fill is selected afterwards.  (One byte per lane and iteration cost 2 100 issue slots per wave — a third
     // of them 64-bit scalar address arithmetic — against 4 600 for the whole tap loop.)
+    int vm = 0; // max |pixel − dc| over the tile rows staged here
     if (g.fw >= 4) {
         for (int r = wave; r < HP_ROWS; r += NW) {
             const int a = a0 + r, gi = ti0 + a;
@@ -109,6 +123,8 @@ __device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restr
                 for (int i = 0; i < 4; ++i) {
                     const int c = c0 + i, gj = gj0 + i;
                     const int px = (rowok && gj >= 0 && gj < g.fw) ? (int)((w >> (8 * ((gj - gj0c) & 3))) & 0xffu) : g.fill;
+                    const int v = (c < tg.TWin && a < tg.NA) ? px - dc : 0;
+                    vm = max(vm, abs(v));
                     if (c < tg.pitchA) dst[c] = (c < tg.TWin) ? (float)(px - dc) : 0.f;
                 }
             }
@@ -122,9 +138,15 @@ __device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restr
                 const int gj = wj0 + c;
                 int v = g.fill;
                 if (rowok && c < tg.TWin && gj >= 0 && gj < g.fw) v = src[gj];
+                if (c < tg.TWin && a < tg.NA) vm = max(vm, abs(v - dc));
                 A[r * tg.pitchA + c] = (c < tg.TWin) ? (float)(v - dc) : 0.f;
             }
         }
+    }
+    if (tg.vmax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vm = max(vm, __shfl_xor(vm, off, 64));
+        if (lane == 0 && vm > 0) atomicMax(&tg.vmax[tg.win0 + b_local], vm);
     }
     __syncthreads();
     const tap_ptr taps = as_taps(taps_row);
@@ -163,9 +185,14 @@ __device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restr
         };
         const int nb = H / U;
         int bk = 0;
+        f2 tot[P]; // the finished chains' sums (blocked accumulation, see the top of the file)
+#pragma unroll
+        for (int o = 0; o < P; ++o) tot[o] = f2{0.f, 0.f};
         for (; bk + NB <= nb; bk += NB) {
 #pragma unroll
             for (int sb = 0; sb < NB; ++sb) block(sb, (bk + sb) * U);
+#pragma unroll
+            for (int o = 0; o < P; ++o) { tot[o] = tot[o] + acc[o]; acc[o] = f2{0.f, 0.f}; }
         }
 #pragma unroll
         for (int sb = 0; sb < NB - 1; ++sb)
@@ -184,6 +211,8 @@ __device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restr
 #pragma unroll
             for (int o = 0; o < P; ++o) acc[o] = fma_bcast(ld(o + H), t, acc[o]);
         }
+#pragma unroll
+        for (int o = 0; o < P; ++o) acc[o] = tot[o] + acc[o]; // the last (partial) chain joins the others
         if (a < tg.NA) {
             f2 *dst = tg.RT + ((long long)b_local * g.n2 + xb) * tg.NA + a;
 #pragma unroll
@@ -269,13 +298,20 @@ __device__ __forceinline__ Peak hpass_block(const TwoPassGeo &tg, const f2 *__re
         };
         const int nb = (L + U - 1) / U;
         int bk = 0;
+        f2 tot[P]; // the finished chains' sums (blocked accumulation, see the top of the file)
+#pragma unroll
+        for (int o = 0; o < P; ++o) tot[o] = f2{0.f, 0.f};
         for (; bk + NB <= nb; bk += NB) {
 #pragma unroll
             for (int sb = 0; sb < NB; ++sb) block(sb, (bk + sb) * U);
+#pragma unroll
+            for (int o = 0; o < P; ++o) { tot[o] = tot[o] + acc[o]; acc[o] = f2{0.f, 0.f}; }
         }
 #pragma unroll
         for (int sb = 0; sb < NB - 1; ++sb)
             if (bk + sb < nb) block(sb, (bk + sb) * U);
+#pragma unroll
+        for (int o = 0; o < P; ++o) acc[o] = tot[o] + acc[o]; // the last (partial) chain joins the others
         if (r < nrows) {
             const int x = r0 + r;
 #pragma unroll

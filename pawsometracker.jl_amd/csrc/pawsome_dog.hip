@@ -738,6 +738,25 @@ int path_for_batch(const pdog_tracker *t, int n)
     return v.id;
 }
 
+// Exact mode's threshold T = 2δ for the TWO-PASS kernels, which accumulate in blocks (dog_twopass.hpp): every chain is at most
+// one trip of the register ring long (m_r pairs in the row pass, m_c taps per channel in the column pass), B chains are added up.
+//   row pass     |R̂± − R±| ≤ (m_r + B_r + 1)·u·V      (chains γ_m·Σ|terms| ≤ m·u·V in total, B additions of partial sums ≤ V, taps rounded once;
+//                                                       with the symmetric pre-add Σ|terms| = Σ_k g[k]·|v_a + v_b| ≤ V·Σg = V all the same)
+//   column pass  per channel (m_c + B_c)·u·V/255, the two channels added (+2u·V/255), the column taps rounded once (+2u·V/255),
+//                the row errors times Σ|c±| = 1/255 each
+//   ⇒ δ = u·(V/255)·(2(m_r + B_r + 1) + 2(m_c + B_c) + 4)  — l = 293: 136·u·V/255 against (6l + 4) = 1762·u·V/255 for one chain per pass.
+// hr8: the 8-row column-pass kernels (tp_php outputs per task, hp_u taps per block); else the 16-row form <13, 16>.
+float twopass_T(const pdog_tracker *t, bool hr8)
+{
+    const int H = t->L / 2;
+    const int m_r = twopass_ring(t->tp_ph1, t->sw.h1_u), m_c = hr8 ? twopass_ring(t->tp_php, t->sw.hp_u) : twopass_ring(13, 16);
+    const int B_r = (H / t->sw.h1_u) / (m_r / t->sw.h1_u) + 1;
+    const int nbc = (t->L + (hr8 ? t->sw.hp_u : 16) - 1) / (hr8 ? t->sw.hp_u : 16);
+    const int B_c = nbc / (m_c / (hr8 ? t->sw.hp_u : 16)) + 1;
+    const double delta = std::ldexp(1.0, -24) * (2.0 * (m_r + B_r + 1) + 2.0 * (m_c + B_c) + 4.0) * 1.02 + 1e-9;
+    return std::min(t->exact_T, std::nextafter((float)(2.0 * delta), 1.0f));
+}
+
 ExactCtl exact_ctl(const pdog_tracker *t)
 {
     ExactCtl x;
@@ -753,11 +772,13 @@ ExactCtl exact_ctl(const pdog_tracker *t)
 // can hold a near-maximal pixel).  With done_flag set the kernel also publishes the host functor's ticket with
 // window 0's final answer.
 int launch_finish(pdog_tracker *t, const LaunchGeo &g, int slot_w, int slot_last, int32_t *d_out_ij, int32_t *d_done_flag, int32_t done_value,
-                  bool use_mask = false, const float *map = nullptr)
+                  bool use_mask = false, const float *map = nullptr, const int *vmax = nullptr, float T_rescan = 0.f)
 {
     FinishGeo fg;
     fg.g = g;
     fg.map = map;
+    fg.vmax = vmax;
+    fg.T_rescan = T_rescan;
     fg.K64 = t->exact ? t->d_K64 : nullptr;
     fg.g64 = t->d_g64;
     fg.dir = t->darker ? -1.0 : 1.0;
@@ -938,12 +959,13 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
             if (t->dc_cap < n) {
                 if (t->d_dc) (void)hipFree(t->d_dc);
                 t->d_dc = nullptr; t->dc_cap = 0;
-                HIP_TRY(hipMalloc(&t->d_dc, sizeof(int) * (size_t)n));
+                HIP_TRY(hipMalloc(&t->d_dc, sizeof(int) * 2 * (size_t)n)); // [n] DC levels, then [n] the windows' own V (exact mode)
                 t->dc_cap = n;
             }
         }
         tg.RT = t->d_V;
         tg.dc = t->d_dc;
+        tg.vmax = nullptr;
         tg.counter = nullptr;
         tg.out_ij = d_out_ij;
         tg.done_flag = nullptr;
@@ -982,7 +1004,14 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
             HIP_TRY(hipGetLastError());
             return PDOG_OK;
         }
-        hipLaunchKernelGGL(dog_dc_kernel, dim3(n), dim3(64), 0, t->stream, g, t->d_dc);
+        // exact mode: the row pass collects each window's own V = max |pixel − dc| (the error bound is proportional to it) and the
+        // finishing kernel flags with it; the two-pass kernels' own bound (blocked accumulation) replaces the one-chain bound
+        if (t->exact && !t->exact_all) {
+            tg.vmax = t->d_dc + t->dc_cap;
+            g.ex.T = twopass_T(t, hr == 8);
+            tg.g.ex.T = g.ex.T;
+        }
+        hipLaunchKernelGGL(dog_dc_kernel, dim3(n), dim3(64), 0, t->stream, g, t->d_dc, tg.vmax);
         HIP_TRY(hipGetLastError());
         for (int w0 = 0; w0 < n; w0 += chunk) {
             const int nw = std::min(chunk, n - w0);
@@ -997,7 +1026,8 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
                 hipLaunchKernelGGL((dog_hpass_kernel<13, 16, false>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             HIP_TRY(hipGetLastError());
         }
-        return launch_finish(t, g, hr, 1 << 30, d_out_ij, nullptr, 0, false, t->exact ? map : nullptr);
+        return launch_finish(t, g, hr, 1 << 30, d_out_ij, nullptr, 0, false, t->exact ? map : nullptr, tg.vmax,
+                             tg.vmax ? 0.5f * (g.ex.T + t->exact_T) : 0.f); // a rescan's plain chains against the blocked kernels' maximum: δ_main + δ_plain
     }
     const int grid = round_up(g.nblocks, 8);
     // Exact mode: a batch whose predecessors flagged more than 2 % of their windows writes its responses (the kernels'

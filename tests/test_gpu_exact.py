@@ -252,7 +252,8 @@ def test_response_map_path_equals_rescan_path(pt, monkeypatch):
     wg = np.empty((48, 2), np.int32)
     for b in range(48):
         ci, cj = int(rng.integers(150, 330)), int(rng.integers(200, 440))
-        wide[b][(yy - ci) ** 2 + (xx - cj) ** 2 <= 60 * 60] = 10
+        if b % 2 == 0:   # every other window holds nothing but noise: near-ties whatever the error bound (the two-pass kernels'
+            wide[b][(yy - ci) ** 2 + (xx - cj) ** 2 <= 60 * 60] = 10   # blocked accumulation leaves most DISC windows unflagged since round 3)
         wg[b] = (ci + int(rng.integers(-20, 21)), cj + int(rng.integers(-20, 21)))
     cases = [(frames, guesses, 25, (45, 45), 200), (wide, wg, 120, None, -1)]
     with_map = [run(f, g, tw, ws if ws else (205, 205), v) for f, g, tw, ws, v in cases]
