@@ -5,17 +5,28 @@
 // rank FP32 separable sums.  Exact ties are settled identically by construction; NEAR ties are not: when the two
 // best responses of a window differ by less than the FP32 evaluation error, FP32 may crown the wrong pixel.
 //
-// Guarantee.  Let F(p) be the reference's Float64 value of pixel p and f(p) the FP32 value of any kernel here.
-// |f(p) − F(p)| ≤ δ for every p, with the a-priori bound (u = 2⁻²⁴, V = max |pixel − dc| ≤ 255, l taps):
-//     row pass     R̂± = Σ_k ĝ±[k]·v, one FMA chain of ≤ l terms, taps rounded once:  |R̂± − R±| ≤ (l + 1)·u·V
-//     column pass  one chain of 2l FMAs over terms bounded by Σ|ĉ±||R̂±| ≤ 2V/255:     ≤ 2l·u·2V/255
-//                  + the row errors times Σ|c±| = 1/255 each + the column taps' rounding 2u·V/255
-//     ⇒ δ = u·(V/255)·(6l + 4)·(1 + ε)  + the reference's own Float64 rounding (≤ l²·2⁻⁵³·2·V/255, negligible)
-// (any summation order, with or without the symmetric pre-add — so it covers every kernel family).  The FLAG uses
-// V = 255: δ(l = 65) = 2.35e-5 against a typical peak of 0.09 and a typical peak-to-neighbour gap of 4.7e-4.  The
-// REFINEMENT of a flagged window may take the window's own V = max |pixel − dc| over its padded tile (refine_window,
-// `tighten`): δ is proportional to it, so a window of ±2-level noise (V ≈ 3) has an 85× smaller T — a handful of
-// candidates instead of thousands, or no near-tie at all (the flag is withdrawn and the FP32 argmax stands).
+// Guarantee.  Let F(p) be the reference's Float64 value of pixel p and f(p) the FP32 value of the kernel that ran.
+// |f(p) − F(p)| ≤ δ for every p, with an a-priori bound that follows THE KERNEL'S OWN OPERATION ORDER (u = 2⁻²⁴,
+// V = max |pixel − dc| ≤ 255).  An FMA chain ŝ_i = fl(ŝ_{i−1} + a_i·b̂_i) rounds each partial sum once:
+//     |ŝ_n − s_n| ≤ u·(1 + u)·Σ_i |ŝ_i|,   |ŝ_i| ≤ V·W_i·(1 + nu),   W_i = Σ_{j ≤ i} |b_j|·max|a_j| / V
+// — the cumulative tap weight in the order the taps are added.  The Gaussians sum to 1 and every kernel adds the kernel's
+// edge taps first, so Σ_i W_i is a fraction of the chain length n that the order-blind bound n·u·V of round 2 charged:
+//     row pass     symmetric pairs from the edge inwards, centre last, v_a + v_b exact:  W_i = Σ_{j ≤ i} 2g[j] (then + g[H]);
+//                  the taps are rounded once (+u·V)                                            ⇒ |R̂± − R±| ≤ u·V·(Σ_i W_i + 1)
+//     column pass  terms bounded by |ĉ±|·|R̂±| ≤ c±·V/255: the same sum over the column taps' cumulative weights — per channel
+//                  where the two Gaussians keep separate chains and are added at the end (+2 for that addition and the rounded
+//                  taps), both weights per step where one f32 takes the (+, −) terms alternately (roll kernels); plus the row
+//                  errors times Σ|c±| = 1/255 each
+//     ⇒ δ = u·(V/255)·F·1.02, F evaluated numerically over the tracker's own Float64 taps per kernel FAMILY (pawsome_dog.hip,
+//       exact_factors): l = 65: F = 157 (roll), 94 (fused, tiled), 138 (ring) against 6l + 4 = 394; the two-pass kernels add
+//       every chain of one register-ring trip from zero and sum the chains (dog_twopass.hpp): l = 293: F = 72 against 1762.
+// The reference's own Float64 rounding (≤ l²·2⁻⁵³·2·V/255) is negligible beside it.  The FLAG uses V = 255 (δ(l = 65) = 9.5e-6
+// for the roll kernels against a typical peak of 0.09 and a typical peak-to-neighbour gap of 4.7e-4) or, on the two-pass path,
+// the window's own V, which its row pass collects.  The REFINEMENT of a flagged window may take the window's own
+// V = max |pixel − dc| over its padded tile (refine_window, `tighten`): δ is proportional to it, so a window of ±2-level noise
+// (V ≈ 3) has an 85× smaller T — a handful of candidates instead of thousands, or no near-tie at all (the flag is withdrawn
+// and the FP32 argmax stands).  Values the refinement RECOMPUTES in FP32 (plain chains: F_rescan) are compared with the main
+// kernel's maximum under δ_main + δ_rescan (ExactCtl::T_rescan), the main kernel's own values under 2δ_main (ExactCtl::T).
 //   1. Every main kernel also tracks the RUNNER-UP value of its window (Peak, dog_kernels.hpp).  If best − runner-up > 2δ
 //      the FP32 argmax is the reference's argmax (the true argmax p* has f(p*) ≥ F(p*) − δ ≥ F(p̂) − δ ≥ f(p̂) − 2δ,
 //      so it is p̂ itself) and nothing else happens: ≈99 % of blob windows.
@@ -775,7 +786,6 @@ struct FinishGeo {
     int v_after;                 // RefineCtx::v_after
     const float *map;            // null, or the batch's FP32 responses [n][n2][n1] (two-pass path): refine_window reads the candidates off it
     const int *vmax;             // null, or [n]: each window's own V = max |pixel − dc| (two-pass row pass): the flag and the refinement scale T with V/255
-    float T_rescan;              // RefineCtx::T_rescan (0: same as g.ex.T)
     int32_t *out_ij;             // [n][2]
     int32_t *done_flag;          // NULL or host-coherent ticket word (see dog_fused.hpp): published with window 0's final answer
     int32_t done_value;
@@ -874,7 +884,7 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
         c.second = s_sec2[w];
         c.fp32_idx = s_idx2[w];
         c.v_after = fg.v_after;
-        c.T_rescan = fg.T_rescan;
+        c.T_rescan = g.ex.T_rescan;
         c.vmax_known = fg.vmax ? fg.vmax[b] : -1;
         c.cbw = fg.cbw;
         c.tile_rows = fg.tile_rows;

@@ -339,6 +339,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
             c.dir = rp->dir;
             c.T64 = rp->T64;
             c.T = g.ex.T;
+            c.T_rescan = g.ex.T_rescan;
             c.second = s_sec2;
             c.fp32_idx = s_idx2;
             c.cbw = fg.ref_cbw;

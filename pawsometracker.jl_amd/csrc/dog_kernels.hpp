@@ -80,7 +80,8 @@ __device__ __forceinline__ void peak_wave_reduce(Peak &p, int width = 64)
 struct ExactCtl {
     unsigned long long *stat; // [4] since the tracker was created: windows refined, column blocks rescanned, candidates, sequential chains run (diagnostics)
     int *range_err;           // host-coherent words: [0] set when a guess lies where the reference raises BoundsError (:45-46) (2: a device-side wait gave up); [1] windows flagged for refinement by the finishing kernel, cumulative
-    float T;                  // 2δ
+    float T;                  // 2δ_main: the launched kernel family's own error bound (pawsome_dog.hip, exact_factors) for |pixel − dc| ≤ 255
+    float T_rescan;           // δ_main + δ_rescan: the refinement's recomputed FP32 values (plain chains) against the main kernel's maximum
 };
 // The reference's PaddedView extends radii + l past the frame (:45-46) and the filter reads radii + l÷2 around the
 // guess: a guess outside [−l÷2, sz + l÷2 + 1] raises BoundsError there.  Device-resident guesses cannot be checked

@@ -630,6 +630,7 @@ __global__ __launch_bounds__(512) void dog_chain_kernel(const ChainGeo cg, const
             c.dir = rp->dir;
             c.T64 = rp->T64;
             c.T = g.ex.T;
+            c.T_rescan = g.ex.T_rescan;
             c.second = s_sec2;
             c.fp32_idx = s_idx2;
             c.cbw = cg.ref_cbw;

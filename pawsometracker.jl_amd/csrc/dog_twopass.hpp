@@ -51,6 +51,9 @@ struct TwoPassGeo {
 // bound δ(l = 293) = 1.05e-4 exceeded the distance between NEIGHBOURING responses at σ = 51 (≈2e-5): exact mode flagged and
 // re-decided every cfg5 window.  Cost: one v_pk_add_f32 + one v_mov_b64 per output and trip (≈+4 % instructions).
 // Every output still sees the same operations in the same order: equal inputs give bit-equal outputs, flat windows tie exactly.
+// FLUSH instances serve kernel lengths from TWOPASS_FLUSH_L on (the plain instances keep 70–96 VGPRs instead of 118–150 and serve the
+// short kernels' small batches, where the plain chains' bound already flags next to nothing).
+constexpr int TWOPASS_FLUSH_L = 101;
 __host__ __device__ constexpr int twopass_ring(int P, int U) { return ((P + 2 * U - 1 + U - 1) / U) * U; } // register-ring slots = taps per trip
 
 static __global__ __launch_bounds__(64) void dog_dc_kernel(const LaunchGeo g, int *__restrict__ dc, int *__restrict__ vmax)
@@ -75,7 +78,7 @@ constexpr int HP_ROWS = 16; // rows per workgroup in both passes
 // One row-pass workgroup's work: tile rows 16·rb … of the window whose RT block is `b_local`, read from `frame` around
 // guess (g1, g2).  DCIN: derive the DC level here; otherwise dc_in is used.  (The kernels below and the cooperative
 // single-clip chain, dog_coop.hpp, share it.)
-template <int P, int U, bool DCIN>
+template <int P, int U, bool DCIN, bool FLUSH>
 __device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restrict__ taps_row, unsigned char *smem, int b_local, int rb,
                                          const uint8_t *__restrict__ frame, int g1, int g2, int dc_in)
 {
@@ -123,8 +126,7 @@ __device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restr
                 for (int i = 0; i < 4; ++i) {
                     const int c = c0 + i, gj = gj0 + i;
                     const int px = (rowok && gj >= 0 && gj < g.fw) ? (int)((w >> (8 * ((gj - gj0c) & 3))) & 0xffu) : g.fill;
-                    const int v = (c < tg.TWin && a < tg.NA) ? px - dc : 0;
-                    vm = max(vm, abs(v));
+                    if (FLUSH) vm = max(vm, (c < tg.TWin && a < tg.NA) ? abs(px - dc) : 0); // (the plain instances do not collect V)
                     if (c < tg.pitchA) dst[c] = (c < tg.TWin) ? (float)(px - dc) : 0.f;
                 }
             }
@@ -138,12 +140,12 @@ __device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restr
                 const int gj = wj0 + c;
                 int v = g.fill;
                 if (rowok && c < tg.TWin && gj >= 0 && gj < g.fw) v = src[gj];
-                if (c < tg.TWin && a < tg.NA) vm = max(vm, abs(v - dc));
+                if (FLUSH && c < tg.TWin && a < tg.NA) vm = max(vm, abs(v - dc));
                 A[r * tg.pitchA + c] = (c < tg.TWin) ? (float)(v - dc) : 0.f;
             }
         }
     }
-    if (tg.vmax) {
+    if (FLUSH && tg.vmax) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) vm = max(vm, __shfl_xor(vm, off, 64));
         if (lane == 0 && vm > 0) atomicMax(&tg.vmax[tg.win0 + b_local], vm);
@@ -185,14 +187,16 @@ __device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restr
         };
         const int nb = H / U;
         int bk = 0;
-        f2 tot[P]; // the finished chains' sums (blocked accumulation, see the top of the file)
+        f2 tot[FLUSH ? P : 1]; // the finished chains' sums (blocked accumulation, see the top of the file)
 #pragma unroll
-        for (int o = 0; o < P; ++o) tot[o] = f2{0.f, 0.f};
+        for (int o = 0; o < (FLUSH ? P : 1); ++o) tot[o] = f2{0.f, 0.f};
         for (; bk + NB <= nb; bk += NB) {
 #pragma unroll
             for (int sb = 0; sb < NB; ++sb) block(sb, (bk + sb) * U);
+            if (FLUSH) {
 #pragma unroll
-            for (int o = 0; o < P; ++o) { tot[o] = tot[o] + acc[o]; acc[o] = f2{0.f, 0.f}; }
+                for (int o = 0; o < P; ++o) { tot[o] = tot[o] + acc[o]; acc[o] = f2{0.f, 0.f}; }
+            }
         }
 #pragma unroll
         for (int sb = 0; sb < NB - 1; ++sb)
@@ -211,8 +215,10 @@ __device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restr
 #pragma unroll
             for (int o = 0; o < P; ++o) acc[o] = fma_bcast(ld(o + H), t, acc[o]);
         }
+        if (FLUSH) {
 #pragma unroll
-        for (int o = 0; o < P; ++o) acc[o] = tot[o] + acc[o]; // the last (partial) chain joins the others
+            for (int o = 0; o < P; ++o) acc[o] = tot[o] + acc[o]; // the last (partial) chain joins the others
+        }
         if (a < tg.NA) {
             f2 *dst = tg.RT + ((long long)b_local * g.n2 + xb) * tg.NA + a;
 #pragma unroll
@@ -222,7 +228,7 @@ __device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restr
     }
 }
 
-template <int P, int U, bool DCIN = false>
+template <int P, int U, bool DCIN = false, bool FLUSH = false>
 __global__ __launch_bounds__(256) void dog_h1_kernel(const TwoPassGeo tg, const f2 *__restrict__ taps_row)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256) void dog_h1_kernel(const TwoPassGeo tg, const 
     const int rb = blockIdx.x - b_local * tg.h1blocks_per_win;
     const int b = tg.win0 + b_local;
     const int fidx = g.frame_index ? g.frame_index[b] : b;
-    h1_block<P, U, DCIN>(tg, taps_row, smem, b_local, rb, g.frames + (long long)fidx * g.frame_stride, g.guesses[2 * b], g.guesses[2 * b + 1],
+    h1_block<P, U, DCIN, FLUSH>(tg, taps_row, smem, b_local, rb, g.frames + (long long)fidx * g.frame_stride, g.guesses[2 * b], g.guesses[2 * b + 1],
                          DCIN ? 0 : tg.dc[b]);
 }
 
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256) void dog_h1_kernel(const TwoPassGeo tg, const 
 // device-scope counter on the writer side, device-scope loads on the reader side; the counter is left at zero.
 // One column-pass workgroup's work on RT block `b_local`, window columns HR·rb …: the workgroup's peak, valid in thread 0
 // (ends with a barrier: the caller may reuse the LDS).  b: the window's index for the optional response output.
-template <int P, int U, bool RESP, int HR>
+template <int P, int U, bool RESP, int HR, bool FLUSH>
 __device__ __forceinline__ Peak hpass_block(const TwoPassGeo &tg, const f2 *__restrict__ taps_col, unsigned char *smem, int b_local, int rb, int b)
 {
     const LaunchGeo &g = tg.g;
@@ -298,20 +304,24 @@ __device__ __forceinline__ Peak hpass_block(const TwoPassGeo &tg, const f2 *__re
         };
         const int nb = (L + U - 1) / U;
         int bk = 0;
-        f2 tot[P]; // the finished chains' sums (blocked accumulation, see the top of the file)
+        f2 tot[FLUSH ? P : 1]; // the finished chains' sums (blocked accumulation, see the top of the file)
 #pragma unroll
-        for (int o = 0; o < P; ++o) tot[o] = f2{0.f, 0.f};
+        for (int o = 0; o < (FLUSH ? P : 1); ++o) tot[o] = f2{0.f, 0.f};
         for (; bk + NB <= nb; bk += NB) {
 #pragma unroll
             for (int sb = 0; sb < NB; ++sb) block(sb, (bk + sb) * U);
+            if (FLUSH) {
 #pragma unroll
-            for (int o = 0; o < P; ++o) { tot[o] = tot[o] + acc[o]; acc[o] = f2{0.f, 0.f}; }
+                for (int o = 0; o < P; ++o) { tot[o] = tot[o] + acc[o]; acc[o] = f2{0.f, 0.f}; }
+            }
         }
 #pragma unroll
         for (int sb = 0; sb < NB - 1; ++sb)
             if (bk + sb < nb) block(sb, (bk + sb) * U);
+        if (FLUSH) {
 #pragma unroll
-        for (int o = 0; o < P; ++o) acc[o] = tot[o] + acc[o]; // the last (partial) chain joins the others
+            for (int o = 0; o < P; ++o) acc[o] = tot[o] + acc[o]; // the last (partial) chain joins the others
+        }
         if (r < nrows) {
             const int x = r0 + r;
 #pragma unroll
@@ -335,7 +345,7 @@ __device__ __forceinline__ Peak hpass_block(const TwoPassGeo &tg, const f2 *__re
     return pk;
 }
 
-template <int P, int U, bool RESP, int HR = HP_ROWS, bool FIN = false>
+template <int P, int U, bool RESP, int HR = HP_ROWS, bool FIN = false, bool FLUSH = false>
 __global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, const f2 *__restrict__ taps_col)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(256) void dog_hpass_kernel(const TwoPassGeo tg, con
     const int b_local = blockIdx.x / tg.hblocks_per_win;
     const int rb = blockIdx.x - b_local * tg.hblocks_per_win;
     const int b = tg.win0 + b_local;
-    Peak pk = hpass_block<P, U, RESP, HR>(tg, taps_col, smem, b_local, rb, b);
+    Peak pk = hpass_block<P, U, RESP, HR, FLUSH>(tg, taps_col, smem, b_local, rb, b);
     __shared__ int s_last;
     if (tid == 0) {
         if (FIN) {

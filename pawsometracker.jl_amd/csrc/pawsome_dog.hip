@@ -314,7 +314,8 @@ struct pdog_tracker {
     // reference's own Float64 arithmetic
     bool exact = true;
     bool exact_all = false;           // pdog_set_exact(t, 2): refine every window with an infinite threshold (tests: the whole reference computation on the device)
-    float exact_T = 0.f;              // 2δ
+    std::vector<double> h_gp, h_gm;   // the two Float64 Gaussians (host copy): the error bounds follow the kernels' operation order over THESE taps
+    double F_sym_int = 0, F_sym_sep = 0, F_ring = 0, F_rescan = 0; // error-bound factors per kernel family (exact_factors)
     double *d_K64 = nullptr;          // dir·(g₊⊗g₊ − g₋⊗g₋), l×l column-major, Float64 (:41-43)
     double *d_g64 = nullptr;          // [2][l] the two normalised Gaussians in Float64 (the refinement's separable stage)
     RefineParams *d_rp = nullptr;     // {K64, g64, dir, T64} for the kernels that refine inline
@@ -365,43 +366,56 @@ int twopass_pitch(int nout, int L, int rows = HP_ROWS) { return twopass_pitch_q(
 //   205 tall, l = 293:  P = 5 3.44 ms, 7 2.50, 9 2.57, 13 3.45
 // ⇒ P = 7 unless P = 9 fills its rounds better.
 typedef void (*tp_fn)(TwoPassGeo, const f2 *);
-tp_fn h1_kernel_for(int P, bool dcin, int U = 8)
+// flush: the blocked-accumulation instances (dog_twopass.hpp), for kernel lengths from TWOPASS_FLUSH_L on.  The product build
+// holds the default block sizes only (row pass 4 taps, column pass 8); the diagnostic build adds the 8- / 16-tap instances.
+tp_fn h1_kernel_for(int P, bool dcin, int U, bool flush)
 {
-    if (U == 4) {
-        switch (P) {
-        case 9: return dcin ? (tp_fn)dog_h1_kernel<9, 4, true> : (tp_fn)dog_h1_kernel<9, 4, false>;
-        case 17: return dcin ? (tp_fn)dog_h1_kernel<17, 4, true> : (tp_fn)dog_h1_kernel<17, 4, false>;
-        case 11: return dcin ? (tp_fn)dog_h1_kernel<11, 4, true> : (tp_fn)dog_h1_kernel<11, 4, false>;
-        default: return dcin ? (tp_fn)dog_h1_kernel<13, 4, true> : (tp_fn)dog_h1_kernel<13, 4, false>;
-        }
-    }
-    switch (P) {
-    case 5: return dcin ? (tp_fn)dog_h1_kernel<5, 8, true> : (tp_fn)dog_h1_kernel<5, 8, false>;
-    case 7: return dcin ? (tp_fn)dog_h1_kernel<7, 8, true> : (tp_fn)dog_h1_kernel<7, 8, false>;
-    case 9: return dcin ? (tp_fn)dog_h1_kernel<9, 8, true> : (tp_fn)dog_h1_kernel<9, 8, false>;
-    case 11: return dcin ? (tp_fn)dog_h1_kernel<11, 8, true> : (tp_fn)dog_h1_kernel<11, 8, false>;
-    case 17: return dcin ? (tp_fn)dog_h1_kernel<17, 8, true> : (tp_fn)dog_h1_kernel<17, 8, false>;
-    default: return dcin ? (tp_fn)dog_h1_kernel<13, 8, true> : (tp_fn)dog_h1_kernel<13, 8, false>;
-    }
-}
-tp_fn hpass8_kernel_for(int P, bool resp, bool fin, int U = 16)
-{
-#define PDOG_HP8(PP, UU) (fin ? (resp ? (tp_fn)dog_hpass_kernel<PP, UU, true, 8, true> : (tp_fn)dog_hpass_kernel<PP, UU, false, 8, true>) \
-                              : (resp ? (tp_fn)dog_hpass_kernel<PP, UU, true, 8, false> : (tp_fn)dog_hpass_kernel<PP, UU, false, 8, false>))
+#define PDOG_H1(PP, UU) (flush ? (dcin ? (tp_fn)dog_h1_kernel<PP, UU, true, true> : (tp_fn)dog_h1_kernel<PP, UU, false, true>) \
+                               : (dcin ? (tp_fn)dog_h1_kernel<PP, UU, true, false> : (tp_fn)dog_h1_kernel<PP, UU, false, false>))
+#ifdef PDOG_ABLATIONS
     if (U == 8) {
         switch (P) {
-        case 5: return PDOG_HP8(5, 8);
-        case 9: return PDOG_HP8(9, 8);
-        case 13: return PDOG_HP8(13, 8);
-        default: return PDOG_HP8(7, 8);
+        case 5: return PDOG_H1(5, 8);
+        case 7: return PDOG_H1(7, 8);
+        case 9: return PDOG_H1(9, 8);
+        case 11: return PDOG_H1(11, 8);
+        case 17: return PDOG_H1(17, 8);
+        default: return PDOG_H1(13, 8);
         }
     }
+#endif
+    (void)U;
     switch (P) {
-    case 5: return PDOG_HP8(5, 16);
-    case 9: return PDOG_HP8(9, 16);
-    default: return PDOG_HP8(7, 16);
+    case 9: return PDOG_H1(9, 4);
+    case 17: return PDOG_H1(17, 4);
+    case 11: return PDOG_H1(11, 4);
+    default: return PDOG_H1(13, 4);
+    }
+#undef PDOG_H1
+}
+tp_fn hpass8_kernel_for(int P, bool resp, bool fin, int U, bool flush)
+{
+#define PDOG_HP8F(PP, UU, FF) (fin ? (resp ? (tp_fn)dog_hpass_kernel<PP, UU, true, 8, true, FF> : (tp_fn)dog_hpass_kernel<PP, UU, false, 8, true, FF>) \
+                                   : (resp ? (tp_fn)dog_hpass_kernel<PP, UU, true, 8, false, FF> : (tp_fn)dog_hpass_kernel<PP, UU, false, 8, false, FF>))
+#define PDOG_HP8(PP, UU) (flush ? PDOG_HP8F(PP, UU, true) : PDOG_HP8F(PP, UU, false))
+#ifdef PDOG_ABLATIONS
+    if (U == 16) {
+        switch (P) {
+        case 5: return PDOG_HP8(5, 16);
+        case 9: return PDOG_HP8(9, 16);
+        default: return PDOG_HP8(7, 16);
+        }
+    }
+#endif
+    (void)U;
+    switch (P) {
+    case 5: return PDOG_HP8(5, 8);
+    case 9: return PDOG_HP8(9, 8);
+    case 13: return PDOG_HP8(13, 8);
+    default: return PDOG_HP8(7, 8);
     }
 #undef PDOG_HP8
+#undef PDOG_HP8F
 }
 int pick_h1_outputs(int nout)
 {
@@ -441,7 +455,8 @@ size_t fused_total_lds(const pdog_tracker *t)
 }
 
 int ensure_capacity(pdog_tracker *t, int n);
-ExactCtl exact_ctl(const pdog_tracker *t);
+enum KernelFamily : int { kFamRoll, kFamRing, kFamFused, kFamTwoPass8, kFamTwoPass16 };
+ExactCtl exact_ctl(const pdog_tracker *t, KernelFamily fam);
 
 // Outputs per task of the fused / tiled kernels: fewest rounds of 1024 tasks, then least work per task (≈ P outputs + a fixed cost)
 int pick_outputs_per_task(int lines, int nout, std::initializer_list<int> ps, double fixed)
@@ -550,7 +565,7 @@ int launch_tiled(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     g.part_idx = t->d_part_idx;
     g.part_sec = t->d_part_sec;
     g.part_mask = t->d_part_mask;
-    g.ex = exact_ctl(t);
+    g.ex = exact_ctl(t, kFamFused);
     g.fh = FH; g.fw = FW; g.r1 = t->r1; g.r2 = t->r2; g.n1 = t->n1; g.n2 = t->n2;
     g.L = t->L; g.fill = t->fill; g.nstrips = nsub; g.nslots = nsub; g.n = n; g.nblocks = n * nsub;
     tg.NA = t->n1 + t->L - 1;
@@ -660,9 +675,9 @@ int choose_variant(pdog_tracker *t, int forced)
             }
             for (bool resp : {false, true})
                 for (bool fin : {false, true})
-                    if (int rc = raise_lds_limit((const void *)hpass8_kernel_for(t->tp_php, resp, fin, t->sw.hp_u), hl8)) return rc;
+                    if (int rc = raise_lds_limit((const void *)hpass8_kernel_for(t->tp_php, resp, fin, t->sw.hp_u, t->L >= TWOPASS_FLUSH_L), hl8)) return rc;
             for (bool dcin : {false, true})
-                if (int rc = raise_lds_limit((const void *)h1_kernel_for(t->tp_ph1, dcin, t->sw.h1_u), h1l)) return rc;
+                if (int rc = raise_lds_limit((const void *)h1_kernel_for(t->tp_ph1, dcin, t->sw.h1_u, t->L >= TWOPASS_FLUSH_L), h1l)) return rc;
             t->small_twopass = true;
         }
     }
@@ -738,31 +753,76 @@ int path_for_batch(const pdog_tracker *t, int n)
     return v.id;
 }
 
-// Exact mode's threshold T = 2δ for the TWO-PASS kernels, which accumulate in blocks (dog_twopass.hpp): every chain is at most
-// one trip of the register ring long (m_r pairs in the row pass, m_c taps per channel in the column pass), B chains are added up.
-//   row pass     |R̂± − R±| ≤ (m_r + B_r + 1)·u·V      (chains γ_m·Σ|terms| ≤ m·u·V in total, B additions of partial sums ≤ V, taps rounded once;
-//                                                       with the symmetric pre-add Σ|terms| = Σ_k g[k]·|v_a + v_b| ≤ V·Σg = V all the same)
-//   column pass  per channel (m_c + B_c)·u·V/255, the two channels added (+2u·V/255), the column taps rounded once (+2u·V/255),
-//                the row errors times Σ|c±| = 1/255 each
-//   ⇒ δ = u·(V/255)·(2(m_r + B_r + 1) + 2(m_c + B_c) + 4)  — l = 293: 136·u·V/255 against (6l + 4) = 1762·u·V/255 for one chain per pass.
-// hr8: the 8-row column-pass kernels (tp_php outputs per task, hp_u taps per block); else the 16-row form <13, 16>.
-float twopass_T(const pdog_tracker *t, bool hr8)
+// ---- exact mode's FP32 error bounds, per kernel family (dog_exact.hpp: the guarantee) ----
+// An FMA chain ŝ_i = fl(ŝ_{i−1} + a_i·b̂_i) satisfies |ŝ_n − s_n| ≤ u·(1 + u)·Σ_i |ŝ_i| (each step rounds its own result once), and
+// |ŝ_i| ≤ V·W_i·(1 + nu) where W_i = Σ_{j ≤ i} |b_j|·max|a_j|/V is the cumulative tap weight IN THE ORDER THE KERNEL ADDS THEM.  The
+// Gaussians sum to 1, so Σ_i W_i is far below the chain length n that the order-blind bound n·u·V charges: the kernels add the
+// smallest taps (the kernel's edges) first.  The factors below are Σ_i W_i evaluated numerically over the tracker's own Float64
+// taps for each family's operation order (+1 per rounded tap table, +2 for a final channel addition); δ = u·(V/255)·F·1.02:
+//   row pass, symmetric pairs from the edge inwards, centre last (roll, thin, fused, tiled, two-pass):  W_i = Σ_{j ≤ i} 2g[j]
+//   row pass, plain chain over the l taps (ring kernels; the refinement's FP32 rescan):               W_i = Σ_{j ≤ i} g[j]
+//   column pass, one f32 per output taking (+, −) terms alternately (roll, thin, folded column, rescan): both cumulative weights per step
+//   column pass, the two Gaussians in separate chains, added at the end (ring, fused, tiled, two-pass)
+//   two-pass: every chain is one trip of the register ring long, the chains' sums are added up (dog_twopass.hpp) — per chain its own
+//   cumulative weights from zero, plus the running total's weight per addition
+// l = 65: 157 (roll) / 94 (fused, tiled) / 138 (ring) against the order-blind 6l + 4 = 394;  l = 293 two-pass: 72 against 1762.
+struct ExactFactors { double sym_int, sym_sep, ring, rescan; };
+ExactFactors exact_factors(const std::vector<double> &gp, const std::vector<double> &gm)
 {
-    const int H = t->L / 2;
-    const int m_r = twopass_ring(t->tp_ph1, t->sw.h1_u), m_c = hr8 ? twopass_ring(t->tp_php, t->sw.hp_u) : twopass_ring(13, 16);
-    const int B_r = (H / t->sw.h1_u) / (m_r / t->sw.h1_u) + 1;
-    const int nbc = (t->L + (hr8 ? t->sw.hp_u : 16) - 1) / (hr8 ? t->sw.hp_u : 16);
-    const int B_c = nbc / (m_c / (hr8 ? t->sw.hp_u : 16)) + 1;
-    const double delta = std::ldexp(1.0, -24) * (2.0 * (m_r + B_r + 1) + 2.0 * (m_c + B_c) + 4.0) * 1.02 + 1e-9;
-    return std::min(t->exact_T, std::nextafter((float)(2.0 * delta), 1.0f));
+    const int l = (int)gp.size(), H = l / 2;
+    auto row_sym = [&](const std::vector<double> &g) { double W = 0, F = 0; for (int k = 0; k <= H; ++k) { W += (k < H ? 2.0 : 1.0) * g[k]; F += W; } return F + 1.0; };
+    auto row_plain = [&](const std::vector<double> &g) { double W = 0, F = 0; for (int k = 0; k < l; ++k) { W += g[k]; F += W; } return F + 1.0; };
+    double Gp = 0, Gm = 0, c_sep = 4.0, c_int = 2.0;
+    for (int t = 0; t < l; ++t) {
+        Gp += gp[t];
+        c_int += Gp + Gm; // after the + term of tap t
+        Gm += gm[t];
+        c_int += Gp + Gm; // after the − term
+        c_sep += Gp + Gm;
+    }
+    ExactFactors f;
+    f.sym_int = row_sym(gp) + row_sym(gm) + c_int;
+    f.sym_sep = row_sym(gp) + row_sym(gm) + c_sep;
+    f.ring = row_plain(gp) + row_plain(gm) + c_sep;
+    f.rescan = row_plain(gp) + row_plain(gm) + c_int;
+    return f;
 }
-
-ExactCtl exact_ctl(const pdog_tracker *t)
+// the two-pass kernels' factor for the tracker's task sizes (hr8: the 8-row column-pass kernels, else the 16-row form <13, 16>)
+double twopass_factor(const pdog_tracker *t, bool hr8)
+{
+    if (!hr8 || t->L < TWOPASS_FLUSH_L) return t->F_sym_sep; // the plain instances: symmetric row pass, separate column chains
+    const int l = t->L, H = l / 2;
+    const int U1 = t->sw.h1_u, m_r = twopass_ring(t->tp_ph1, U1), U2 = hr8 ? t->sw.hp_u : 16, m_c = hr8 ? twopass_ring(t->tp_php, U2) : twopass_ring(13, 16);
+    auto blocked = [](const std::vector<double> &terms, int m, int n_full) { // chains of m terms (n_full of them), then ONE chain with the rest
+        double F = 0, total = 0;
+        const int n = (int)terms.size();
+        for (int c = 0, a = 0; c <= n_full; ++c) {
+            const int b = c < n_full ? a + m : n;
+            double w = 0;
+            for (int i = a; i < b; ++i) { w += terms[i]; F += w; } // the chain's own running sums, from zero
+            total += w;
+            F += total;                                             // the addition that takes the chain's sum into the running total
+            a = b;
+        }
+        return F;
+    };
+    auto row = [&](const std::vector<double> &g) {
+        std::vector<double> terms(H + 1);
+        for (int k = 0; k <= H; ++k) terms[k] = (k < H ? 2.0 : 1.0) * g[k];
+        return blocked(terms, m_r, (H / U1) / (m_r / U1)) + 1.0;
+    };
+    auto col = [&](const std::vector<double> &g) { return blocked(g, m_c, ((l + U2 - 1) / U2) / (m_c / U2)); };
+    return row(t->h_gp) + row(t->h_gm) + col(t->h_gp) + col(t->h_gm) + 4.0;
+}
+ExactCtl exact_ctl(const pdog_tracker *t, KernelFamily fam)
 {
     ExactCtl x;
     x.stat = t->d_ref_stat;
     x.range_err = t->d_mail_map ? t->d_mail_map + 5 : nullptr;
-    x.T = t->exact_all ? __builtin_huge_valf() : t->exact_T;
+    const double F = fam == kFamRoll ? t->F_sym_int : fam == kFamRing ? t->F_ring : fam == kFamFused ? t->F_sym_sep : twopass_factor(t, fam == kFamTwoPass8);
+    const double u = std::ldexp(1.0, -24);
+    x.T = t->exact_all ? __builtin_huge_valf() : std::nextafter((float)(2.0 * u * F * 1.02 + 2e-9), 1.0f);
+    x.T_rescan = t->exact_all ? __builtin_huge_valf() : std::nextafter((float)(u * (F + t->F_rescan) * 1.02 + 2e-9), 1.0f);
     return x;
 }
 
@@ -772,13 +832,12 @@ ExactCtl exact_ctl(const pdog_tracker *t)
 // can hold a near-maximal pixel).  With done_flag set the kernel also publishes the host functor's ticket with
 // window 0's final answer.
 int launch_finish(pdog_tracker *t, const LaunchGeo &g, int slot_w, int slot_last, int32_t *d_out_ij, int32_t *d_done_flag, int32_t done_value,
-                  bool use_mask = false, const float *map = nullptr, const int *vmax = nullptr, float T_rescan = 0.f)
+                  bool use_mask = false, const float *map = nullptr, const int *vmax = nullptr)
 {
     FinishGeo fg;
     fg.g = g;
     fg.map = map;
     fg.vmax = vmax;
-    fg.T_rescan = T_rescan;
     fg.K64 = t->exact ? t->d_K64 : nullptr;
     fg.g64 = t->d_g64;
     fg.dir = t->darker ? -1.0 : 1.0;
@@ -850,7 +909,7 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     fg.ref_cbw = t->fused_ref_cbw;
     fg.ref_rows = t->fused_ref_rows;
     fg.dc_host = dc_host;
-    g.ex = exact_ctl(t);
+    g.ex = exact_ctl(t, kFamFused);
     const size_t lds = fused_total_lds(t);
     typedef fused_fn_t fused_fn;
     fused_fn fn = fused_kernel_for(t->L, d_out_resp != nullptr);
@@ -886,7 +945,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
     g.part_idx = t->d_part_idx;
     g.part_sec = t->d_part_sec;
     g.part_mask = t->d_part_mask;
-    g.ex = exact_ctl(t);
+    g.ex = exact_ctl(t, (v.roll ? kFamRoll : kFamRing));
     g.fh = FH; g.fw = FW; g.r1 = t->r1; g.r2 = t->r2; g.n1 = t->n1; g.n2 = t->n2;
     g.L = t->L; g.fill = t->fill; g.nstrips = t->nstrips; g.n = n;
     g.RR = v.ring(t->L);
@@ -919,6 +978,7 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         g.nstrips = tp_slots;
         g.nslots = tp_slots;
         g.nthin = 0;
+        g.ex = exact_ctl(t, hr == 8 ? kFamTwoPass8 : kFamTwoPass16); // the two-pass kernels' own bound (blocked accumulation)
         // exact mode: the column pass also writes its responses (4 B per pixel), so that a window that needs the
         // refinement — every window, at the σ this path serves — reads its candidates off the map instead of recomputing them
         const float *map = d_out_resp;
@@ -982,9 +1042,9 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         if (lowlat && t->exact) {
             tg.win0 = 0;
             if (ticket_armed) *ticket_armed = d_done_flag != nullptr;
-            hipLaunchKernelGGL(h1_kernel_for(t->tp_ph1, true, t->sw.h1_u), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
+            hipLaunchKernelGGL(h1_kernel_for(t->tp_ph1, true, t->sw.h1_u, t->L >= TWOPASS_FLUSH_L), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
             HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(hpass8_kernel_for(t->tp_php, want_resp, false, t->sw.hp_u), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
+            hipLaunchKernelGGL(hpass8_kernel_for(t->tp_php, want_resp, false, t->sw.hp_u, t->L >= TWOPASS_FLUSH_L), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             HIP_TRY(hipGetLastError());
             return launch_finish(t, g, hr, 1 << 30, d_out_ij, d_done_flag, done_value, false, t->exact ? map : nullptr);
         }
@@ -998,36 +1058,31 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
             tg.done_flag = d_done_flag;
             tg.done_value = done_value;
             if (ticket_armed) *ticket_armed = d_done_flag != nullptr;
-            hipLaunchKernelGGL(h1_kernel_for(t->tp_ph1, true, t->sw.h1_u), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
+            hipLaunchKernelGGL(h1_kernel_for(t->tp_ph1, true, t->sw.h1_u, t->L >= TWOPASS_FLUSH_L), dim3(n * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
             HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(hpass8_kernel_for(t->tp_php, want_resp, true, t->sw.hp_u), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
+            hipLaunchKernelGGL(hpass8_kernel_for(t->tp_php, want_resp, true, t->sw.hp_u, t->L >= TWOPASS_FLUSH_L), dim3(n * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             HIP_TRY(hipGetLastError());
             return PDOG_OK;
         }
         // exact mode: the row pass collects each window's own V = max |pixel − dc| (the error bound is proportional to it) and the
         // finishing kernel flags with it; the two-pass kernels' own bound (blocked accumulation) replaces the one-chain bound
-        if (t->exact && !t->exact_all) {
-            tg.vmax = t->d_dc + t->dc_cap;
-            g.ex.T = twopass_T(t, hr == 8);
-            tg.g.ex.T = g.ex.T;
-        }
+        if (t->exact && !t->exact_all && hr == 8 && t->L >= TWOPASS_FLUSH_L) tg.vmax = t->d_dc + t->dc_cap; // (the blocked-accumulation instances collect it)
         hipLaunchKernelGGL(dog_dc_kernel, dim3(n), dim3(64), 0, t->stream, g, t->d_dc, tg.vmax);
         HIP_TRY(hipGetLastError());
         for (int w0 = 0; w0 < n; w0 += chunk) {
             const int nw = std::min(chunk, n - w0);
             tg.win0 = w0;
-            hipLaunchKernelGGL(h1_kernel_for(t->tp_ph1, false, t->sw.h1_u), dim3(nw * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
+            hipLaunchKernelGGL(h1_kernel_for(t->tp_ph1, false, t->sw.h1_u, t->L >= TWOPASS_FLUSH_L), dim3(nw * tg.h1blocks_per_win), dim3(256), l1, t->stream, tg, (const f2 *)t->d_taps_row);
             HIP_TRY(hipGetLastError());
             if (hr == 8) {
-                hipLaunchKernelGGL(hpass8_kernel_for(t->tp_php, want_resp, false, t->sw.hp_u), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
+                hipLaunchKernelGGL(hpass8_kernel_for(t->tp_php, want_resp, false, t->sw.hp_u, t->L >= TWOPASS_FLUSH_L), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             } else if (want_resp)
                 hipLaunchKernelGGL((dog_hpass_kernel<13, 16, true>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             else
                 hipLaunchKernelGGL((dog_hpass_kernel<13, 16, false>), dim3(nw * tg.hblocks_per_win), dim3(256), l2, t->stream, tg, (const f2 *)t->d_taps_col);
             HIP_TRY(hipGetLastError());
         }
-        return launch_finish(t, g, hr, 1 << 30, d_out_ij, nullptr, 0, false, t->exact ? map : nullptr, tg.vmax,
-                             tg.vmax ? 0.5f * (g.ex.T + t->exact_T) : 0.f); // a rescan's plain chains against the blocked kernels' maximum: δ_main + δ_plain
+        return launch_finish(t, g, hr, 1 << 30, d_out_ij, nullptr, 0, false, t->exact ? map : nullptr, tg.vmax);
     }
     const int grid = round_up(g.nblocks, 8);
     // Exact mode: a batch whose predecessors flagged more than 2 % of their windows writes its responses (the kernels'
@@ -1292,8 +1347,12 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
         dense_dog_kernel(gp.data(), gm.data(), t->L, t->darker != 0, K.data());
         CREATE_TRY(hipMalloc(&t->d_K64, sizeof(double) * K.size()));
         CREATE_TRY(hipMemcpy(t->d_K64, K.data(), sizeof(double) * K.size(), hipMemcpyHostToDevice));
-        const double delta = std::ldexp(1.0, -24) * (6.0 * t->L + 4.0) * 1.02 + 1e-9;
-        t->exact_T = std::nextafter((float)(2.0 * delta), 1.0f);
+        t->h_gp = gp;
+        t->h_gm = gm;
+        {
+            const ExactFactors ef = exact_factors(gp, gm);
+            t->F_sym_int = ef.sym_int; t->F_sym_sep = ef.sym_sep; t->F_ring = ef.ring; t->F_rescan = ef.rescan;
+        }
         CREATE_TRY(hipMalloc(&t->d_ref_stat, sizeof(unsigned long long) * 16)); // [4..7] unused, [8..15]: phase cycles of the refinement (diagnostic build)
         CREATE_TRY(hipMemset(t->d_ref_stat, 0, sizeof(unsigned long long) * 16));
         {
@@ -1513,7 +1572,10 @@ int pdog_get_exact(pdog_tracker *t, int *out_on, double *out_threshold, uint64_t
 {
     if (!t) return fail(PDOG_E_ARG, "pdog_get_exact: null tracker");
     if (out_on) *out_on = t->exact ? 1 : 0;
-    if (out_threshold) *out_threshold = t->exact_all ? (double)__builtin_huge_valf() : (double)t->exact_T;
+    if (out_threshold) { // 2δ of the tracker's batch kernel family (small batches may run another family with a tighter bound)
+        const Variant &v = *t->var;
+        *out_threshold = (double)exact_ctl(t, v.roll ? kFamRoll : v.twopass ? kFamTwoPass8 : v.fused ? kFamFused : kFamRing).T;
+    }
     if (out_refined) {
         if (int rc = drain_and_check(t, "pdog_get_exact")) return rc;
         unsigned long long v = 0;
@@ -1915,7 +1977,7 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
         cg.start = d_start_guesses;
         cg.out_ij = d_out_ij;
         cg.n_frames = n_frames;
-        g.ex = exact_ctl(t);
+        g.ex = exact_ctl(t, kFamRoll);
         cg.rp = t->exact ? t->d_rp : nullptr;
         cg.taps_col_plain = t->d_taps_col;
         // the strips' LDS doubles as the refinement's scratch: the widest block (with its pixel tile if possible) that
