@@ -351,6 +351,11 @@ def run_chain(args):
     frames = torch.from_numpy(frames_h).to(dev)
     start = (int(centres[0, 0]), int(centres[0, 1]))
     bt = pt.BatchTracker(fh, fw, tw, ws, True, fill, device=0)
+    for kv in args.tuning:
+        key, _, val = kv.partition("=")
+        bt.set_tuning(key, int(val or 1))
+    if args.no_exact:
+        bt.set_exact(0)
     bt.use_torch_stream()
     info = bt.info()
     out = torch.empty((n_frames, 2), dtype=torch.int32, device=dev)

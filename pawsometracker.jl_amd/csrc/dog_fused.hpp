@@ -52,6 +52,10 @@ __host__ __device__ constexpr size_t fused_lds_bytes(int n1, int n2, int L) { re
 // (The register-ring windows that removed the shifts from the two-pass kernels were measured here too: SLOWER — 10.8 →
 // 11.6 µs per 45×45 frame, 13.8 → 14.7 µs per 257×257 frame — under the 128-VGPR budget of a 1024-thread workgroup the three
 // unrolled blocks per trip spill, and five P instances of each task triple in code size.)
+// (Round 3: prefetching frame k+1's pixels — the current tile grown by the radii, memory → LDS with global_load_lds_dword
+// behind frame k's staging barrier, frame k+1 then staged and DC-sampled out of LDS — was built and measured on the
+// 100-frame cfg1 chain: 11.84 µs per frame against 11.13 without.  The memory round trip it removes is shorter than the
+// phase stamps suggested; issuing 96 wave-loads and unpacking bytes from LDS costs more.  Dropped.)
 // Runtime kernel length, blocks of U taps.  (Compile-time-l instances with the tap loop fully unrolled were
 // tried for l = 65: 400 SGPR + 300 VGPR spills under the 128-VGPR budget of a 1024-thread workgroup, 2× slower.)
 template <int P, int U>
