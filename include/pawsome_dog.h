@@ -120,14 +120,22 @@ int pdog_set_variant(pdog_tracker *t, int variant);
 int pdog_sync(pdog_tracker *t);
 
 /* Exact mode (default on).  The reference ranks Float64 dense sums (src/PawsomeTracker.jl:57-59); the kernels rank
- * FP32 separable sums whose error is bounded by delta = 2^-24 (6 l + 4).  Every kernel also tracks the runner-up
+ * FP32 separable sums whose error is bounded by delta = 2^-24 * F * V/255, F following each kernel family's own operation
+ * order (l = 65: F = 157 for the batch kernels; csrc/dog_exact.hpp).  Every kernel also tracks the runner-up
  * response of its window; when it lies within 2 delta of the maximum, the window's near-maximal pixels are
- * re-evaluated on the device exactly as the reference evaluates them (dense l x l Float64 correlation, kernel
- * column-major accumulation order) and the first maximum of those values is returned — so a returned position IS
- * the reference's, not merely close to it.  pdog_set_exact(t, 0) switches the re-evaluation off (the FP32 argmax
- * is returned as is); pdog_set_exact(t, 2) re-evaluates EVERY pixel of EVERY window that way (the whole reference
- * computation on the device: a self-check, orders of magnitude slower).  pdog_get_exact: state, the threshold 2 delta, and how many windows have been re-evaluated
- * since the tracker was created (any of the out pointers may be NULL; reading the count drains the stream). */
+ * re-evaluated on the device as this repository's RESTATEMENT of the reference evaluates them (oracle/dog_oracle.c:
+ * dense l x l Float64 correlation, kernel column-major accumulation order) and the first maximum of those values is
+ * returned — so a returned position is the oracle's, not merely close to it.  The oracle is unpinned (no Julia here, no
+ * numeric fixture in the reference); the guarantee is exactly as strong as its two last-bit assumptions: Float64(::N0f8)
+ * is pixel / 255.0 (FixedPointNumbers 0.5-0.8 allowed by Project.toml: some versions multiply by a reciprocal), and
+ * ImageFiltering's FIR inner loop is a strictly sequential `tmp += a*b`, products and sums rounded separately.
+ * pdog_set_exact(t, 0) switches the re-evaluation off (the FP32 argmax
+ * is returned as is); pdog_set_exact(t, 2) re-evaluates EVERY pixel of EVERY window that way (the whole restated
+ * computation on the device: a self-check, orders of magnitude slower).  pdog_get_exact: state, the threshold 2 delta of the
+ * tracker's batch kernels, and how many windows have been re-evaluated since the tracker was created (any of the out
+ * pointers may be NULL; reading the count drains the stream and reports what its kernels raised, like pdog_sync).
+ * pdog_create switches exact mode OFF for windows too tall for the refinement's LDS block (n1 + l beyond ~9000 rows:
+ * pdog_set_exact(t, 1) then fails with PDOG_E_ARG); pdog_get_exact tells. */
 int pdog_set_exact(pdog_tracker *t, int on);
 /* Pins one of the library's alternative code paths on a live tracker — for tests and same-session A/B, not for a host:
  * the defaults are the measured-best choices.  The library reads NO path switch from the environment (only resource

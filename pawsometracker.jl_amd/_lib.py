@@ -123,10 +123,12 @@ def lib():
         L.pdog_group_sync.restype = i; L.pdog_group_sync.argtypes = [p]
         L.pdog_shard_range.restype = i; L.pdog_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
         L.pdog_shard_owner.restype = i; L.pdog_shard_owner.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
-        L.pdog_group_test_compact.restype = i; L.pdog_group_test_compact.argtypes = [p, i, i, p]
+        if hasattr(L, "pdog_group_test_compact"):   # (absent from older builds loaded through PAWSOME_DOG_LIB for an A/B)
+            L.pdog_group_test_compact.restype = i; L.pdog_group_test_compact.argtypes = [p, i, i, p]
     if hasattr(L, "pdog_dense_kernel"):
         L.pdog_dense_kernel.restype = i; L.pdog_dense_kernel.argtypes = [d, i, p, i]
-    L.pdog_set_tuning.restype = i; L.pdog_set_tuning.argtypes = [p, C.c_char_p, i]
+    if hasattr(L, "pdog_set_tuning"):
+        L.pdog_set_tuning.restype = i; L.pdog_set_tuning.argtypes = [p, C.c_char_p, i]
     if hasattr(L, "pdog_set_exact"):
         L.pdog_set_exact.restype = i; L.pdog_set_exact.argtypes = [p, i]
         L.pdog_get_exact.restype = i; L.pdog_get_exact.argtypes = [p, C.POINTER(i), C.POINTER(d), C.POINTER(C.c_uint64)]

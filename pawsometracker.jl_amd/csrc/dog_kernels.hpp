@@ -106,7 +106,7 @@ __device__ __forceinline__ bool wait_counter(const unsigned *ctr, unsigned targe
             }
         }
     }
-    return !(abort && __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return true; // (the counter reached its target: every peer arrived — no second, dependent read of the abort word on the frame's critical path)
 }
 
 __device__ __forceinline__ void range_check(const ExactCtl &x, int g1, int g2, int hw, int fh, int fw)
