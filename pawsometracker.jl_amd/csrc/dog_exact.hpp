@@ -220,7 +220,7 @@ __device__ __forceinline__ int refine_window(const int NT, const LaunchGeo &g, c
     if (tid < 8) cnt[tid] = 0;
     // DC level: the same fixed sample grid as the main kernels (any level in 0…255 keeps the bound)
     int sum = dc_sample_sum(g, frame, ti0, wj0, L, tid, NT);
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    sum = wave_sum(sum);
     if (lane == 0) ired[wave] = sum;
     __syncthreads();
     int tot = 0;

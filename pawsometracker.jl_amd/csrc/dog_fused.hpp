@@ -211,8 +211,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
             load_batch(sr0, v);
             int dc = fg.dc_host;
             if (!host_dc) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) samp += __shfl_xor(samp, off, 64);
+                samp = wave_sum(samp);
                 if (lane == 0) s_sum[wave] = samp;
                 stamp(0);
                 __syncthreads();

@@ -293,8 +293,7 @@ __device__ __forceinline__ void roll_strip(const LaunchGeo &g, const f2 *__restr
     int dc;
     {
         int sum = dc_sample_sum(g, frame, ti0, wj0, L, lane, 64);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        sum = wave_sum(sum);
         dc = dc_from_sum(sum, g.fill);
     }
 
@@ -717,8 +716,7 @@ __global__ __launch_bounds__(256) void dog_thin_kernel(const LaunchGeo g, const 
     int dc;
     {
         int sum = dc_sample_sum(g, frame, ti0, wj0, L, tid, NT);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        sum = wave_sum(sum);
         if (lane == 0) ssum[wave] = sum;
         __syncthreads();
         int tot = 0;

@@ -119,8 +119,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
             load_batch(sr0, v);
             int dc = tg.dc_host;
             if (!host_dc) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) samp += __shfl_xor(samp, off, 64);
+                samp = wave_sum(samp);
                 if (lane == 0) s_sum[wave] = samp;
                 __syncthreads();
                 int total = 0;

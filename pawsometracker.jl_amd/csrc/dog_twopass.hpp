@@ -63,8 +63,7 @@ static __global__ __launch_bounds__(64) void dog_dc_kernel(const LaunchGeo g, in
     const int fidx = g.frame_index ? g.frame_index[b] : b;
     const uint8_t *__restrict__ frame = g.frames + (long long)fidx * g.frame_stride;
     int sum = dc_sample_sum(g, frame, g1 - g.r1 - 1 - hw, g2 - g.r2 - 1 - hw, g.L, lane, 64);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    sum = wave_sum(sum);
     if (lane == 0) {
         dc[b] = dc_from_sum(sum, g.fill);
         if (vmax) vmax[b] = 0; // collected by the row pass that follows
@@ -94,8 +93,7 @@ __device__ __forceinline__ void h1_block(const TwoPassGeo &tg, const f2 *__restr
     if (DCIN) {
         __shared__ int s_dcsum[NW];
         int sum = dc_sample_sum(g, frame, ti0, wj0, L, tid, NT);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        sum = wave_sum(sum);
         if (lane == 0) s_dcsum[wave] = sum;
         __syncthreads();
         int total = 0;
