@@ -19,6 +19,7 @@
 #pragma once
 #include "dog_twopass.hpp"
 #include "dog_exact.hpp"
+#include "dog_roll.hpp"
 
 namespace pdog {
 
@@ -132,20 +133,78 @@ __device__ __forceinline__ void fused_col_task(const f2 *a, int L, tap_ptr taps,
     }
 }
 
+// ---- compile-time kernel length (LT > 0): the default tracker's l = 65 and a few others (fused_has_instance) ----
+// Round 2's attempt unrolled the generic tasks with every tap in SGPRs (400 SGPR + 300 VGPR spills).  This one takes the roll
+// kernel's row pass (dog_roll.hpp: aligned register pairs out of ds_read_b128 quads, 4-tap blocks with their taps loaded
+// beside them — ≈90 VGPRs, no shifts) and a column pass whose sliding window is a register ring with constant indices.
+// The tile then lives in the roll kernel's layout: rows on a pitch of whole bank rows, skewed by {0, 1, 8, 9} 16-byte slots
+// by (row & 3), so that the b128 reads of a lane group (rows r, r+1 × 8 output groups) are conflict free.  Same operation
+// order per output as the runtime-length tasks above: the two kernels' responses are bit-identical.
+__host__ __device__ constexpr bool fused_has_instance(int L) { return L == 65; }
+__host__ __device__ constexpr int fusedc_pitch_a(int n2, int L) { return (8 * ((n2 + 7) / 8) + L + 39 + 63) / 64 * 64; }
+__host__ __device__ constexpr size_t fusedc_a_bytes(int n1, int n2, int L) { return ((size_t)(n1 + L - 1) * fusedc_pitch_a(n2, L) + 64) * 4; }
+__host__ __device__ constexpr size_t fusedc_lds_bytes(int n1, int n2, int L) { return fusedc_a_bytes(n1, n2, L) + (size_t)n2 * fused_pitch_v(n1, L) * 8; }
+__device__ __forceinline__ int fusedc_row_base(int r, int pitch) { return r * pitch + 4 * ((r & 1) + ((r & 2) ? 8 : 0)); }
+
+// P outputs of one window column, l known: taps in blocks of 8 (one s_load_dwordx16 each, requested a block ahead), the window
+// entry e lives in register e mod (P − 1 + 16) — constant after unrolling, so nothing is ever shifted.
+template <int L, int P>
+__device__ __forceinline__ void fusedc_col_task(const f2 *a, tap_ptr taps, f2 (&acc)[P])
+{
+    constexpr int U = 8, NB = L / U, R = L - U * NB, W = P - 1 + 2 * U;
+    static_assert(R >= 1 && R < U, "kernel lengths are odd");
+    f2 win[W];
+#pragma unroll
+    for (int o = 0; o < P; ++o) acc[o] = f2{0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < P - 1 + U; ++e) win[e % W] = a[e];
+    f2 tn[U];
+    tap_ptr tb = pin_taps(taps);
+#pragma unroll
+    for (int j = 0; j < U; ++j) tn[j] = tb[j];
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+        f2 t[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) t[j] = tn[j];
+        tb = pin_taps(tb);
+        const tap_ptr tnext = tb + U * (J + 1);
+        constexpr int dummy = 0; (void)dummy;
+        const int nnew = (J + 1 < NB) ? U : R; // the entries and taps the next block (or the tail) needs
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+            if (j < nnew) {
+                tn[j] = tnext[j];
+                win[(U * (J + 1) + P - 1 + j) % W] = a[U * (J + 1) + P - 1 + j];
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[(U * J + u + o) % W], t[u], acc[o]);
+#pragma unroll
+        for (int o = 0; o < P; ++o) pin_acc(acc[o]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u)
+#pragma unroll
+        for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[(U * NB + u + o) % W], tn[u], acc[o]);
+}
+
 // DIAG != 0 (diagnostic builds only): thread 0 of block 0 stamps the phase boundaries of every frame into g.resp
 // (16 floats per frame: shader cycles since the frame's start at 0 samples reduced (wave 0), 4 after the barrier,
 // 1 tile staged, 2 row pass, 5 column pass + wave peak (wave 0), 6 after the barrier, 3 end of frame; then the same
 // in 100 MHz ticks) instead of the response.
-template <bool RESP, int DIAG = 0>
+template <bool RESP, int DIAG = 0, int LT = 0>
 __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, const f2 *__restrict__ taps_row,
                                                              const f2 *__restrict__ taps_col)
 {
     const LaunchGeo &g = fg.g;
     constexpr int NT = FUSED_NT, NW = NT / 64, U = FUSED_U;
-    const int L = g.L, hw = L >> 1, NA = fg.NA;
+    const int L = LT ? LT : g.L, hw = L >> 1, NA = fg.NA;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *A = reinterpret_cast<float *>(smem);
-    f2 *Vs = reinterpret_cast<f2 *>(smem + fused_a_bytes(g.n1, g.n2, L));
+    f2 *Vs = reinterpret_cast<f2 *>(smem + (LT ? fusedc_a_bytes(g.n1, g.n2, L) : fused_a_bytes(g.n1, g.n2, L)));
     __shared__ int s_sum[NW];
     __shared__ float s_val[NW];
     __shared__ int s_idx[NW];
@@ -161,6 +220,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
     // tile columns c ≥ TWin and RT columns a ≥ NA are only ever read by the sliding windows of masked outputs: zero once
     // (and again after a refinement, which uses this LDS as its scratch)
     auto zero_padding = [&]() {
+        if (LT) return; // the compile-time-l tasks read unstaged entries only into outputs that are masked out
         for (int r = wave; r < NA; r += NW)
             for (int c = fg.TWin + lane; c < fg.pitchA; c += 64) A[r * fg.pitchA + c] = 0.f;
         for (int x = wave; x < g.n2; x += NW)
@@ -221,12 +281,32 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
                 for (int w = 0; w < NW; ++w) total += s_sum[w];
                 dc = dc_from_sum(total, g.fill);
             }
+            const bool colin = gj0 >= 0 && gj0 + 4 <= g.fw;
+            const float fdc = (float)dc;
             for (int r0 = sr0; r0 < NA; r0 += srstep * SU) {
                 if (r0 != sr0) load_batch(r0, v);
 #pragma unroll
                 for (int u = 0; u < SU; ++u) {
                     const int r = r0 + u * srstep, gi = ti0 + r;
                     const bool rowok = gi >= 0 && gi < g.fh;
+                    if (LT) {
+                        // four pixels → one 16-byte store: v_cvt_f32_ubyte0…3 and a packed subtract where the dword lies inside
+                        // the frame (float(px) − float(dc) = float(px − dc) exactly), the per-pixel selection only at the border
+                        if (r < NA && c0 < fg.TWin) {
+                            f4 px;
+                            if (rowok && colin) {
+                                px = f4{(float)(v[u] & 0xffu), (float)((v[u] >> 8) & 0xffu), (float)((v[u] >> 16) & 0xffu), (float)(v[u] >> 24)};
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const int gj = gj0 + i;
+                                    px[i] = (float)((rowok && gj >= 0 && gj < g.fw) ? (int)((v[u] >> (8 * ((gj - gj0c) & 3))) & 0xffu) : g.fill);
+                                }
+                            }
+                            *reinterpret_cast<f4 *>(A + fusedc_row_base(r, fg.pitchA) + c0) = px - fdc;
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int gj = gj0 + i;
@@ -239,7 +319,22 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
         __syncthreads();
         stamp(1);
         // ---- row pass → RT[x][a] ----
-        {
+        if constexpr (LT > 0) {
+            // task = (tile row a, group of 8 outputs), dense over the threads; the division by the group count is a float
+            // multiply (task + ½ never comes within 1/(2·ngx) of a multiple of ngx: exact for every task count that fits LDS)
+            const int ngx = (g.n2 + 7) >> 3, ntask = NA * ngx;
+            const float inv = 1.0f / (float)ngx;
+            for (int task = tid; task < ntask; task += NT) {
+                const int a = (int)(((float)task + 0.5f) * inv), gx = task - a * ngx, xb = 8 * gx;
+                f2 acc[ROLL_P];
+#pragma unroll
+                for (int o = 0; o < ROLL_P; ++o) acc[o] = f2{0.f, 0.f};
+                roll_row_pass<LT>(acc, A + fusedc_row_base(a, fg.pitchA) + xb, trow);
+#pragma unroll
+                for (int o = 0; o < ROLL_P; ++o)
+                    if (xb + o < g.n2) Vs[(xb + o) * fg.pitchV + a] = acc[o];
+            }
+        } else {
             const int ngx = (g.n2 + fg.pr - 1) / fg.pr, ntask = NA * ngx;
             auto run = [&](auto Pc) {
                 constexpr int PR = decltype(Pc)::value;
@@ -269,10 +364,14 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
             const int ngy = (g.n1 + fg.pc - 1) / fg.pc, ntask = g.n2 * ngy;
             auto run = [&](auto Pc) {
                 constexpr int PC = decltype(Pc)::value;
+                const float inv = 1.0f / (float)g.n2;
                 for (int task = tid; task < ntask; task += NT) {
-                    const int gy = task / g.n2, x = task - gy * g.n2, yb = gy * PC;
+                    const int gy = LT ? (int)(((float)task + 0.5f) * inv) : task / g.n2, x = task - gy * g.n2, yb = gy * PC;
                     f2 acc[PC];
-                    fused_col_task<PC, U>(Vs + x * fg.pitchV + yb, L, tcol, acc);
+                    if constexpr (LT > 0)
+                        fusedc_col_task<LT, PC>(Vs + x * fg.pitchV + yb, tcol, acc);
+                    else
+                        fused_col_task<PC, U>(Vs + x * fg.pitchV + yb, L, tcol, acc);
 #pragma unroll
                     for (int o = 0; o < PC; ++o) {
                         const int y = yb + o;

@@ -72,6 +72,7 @@ struct Switches {
     bool no_roll_map = false;             // hard batches on the roll / ring kernels keep recomputing their candidates
     bool no_fold = false;                 // a single remainder column always goes to dog_thin_kernel
     bool fold_always = false;             // … always into the last strip, also below 8 strips per window
+    bool no_fused_c = false;              // the fused kernel's runtime-length instance also where a compile-time-l instance exists
     bool fault_inject = false;            // tests: one sub-window of a tiled chain never delivers its second frame's partial (the device-side waits must give up)
     // tuning and diagnosis (diagnostic build only)
     bool host_trace = false, hpass16 = false, ingest_no_nt = false, ingest_trace = false, fused_diag = false;
@@ -272,6 +273,7 @@ struct pdog_tracker {
     bool forced_variant = false;   // pdog_set_variant pinned the kernel: no batch-size switching
     bool small_twopass = false;    // two-pass kernels are set up and may take over small batches
     bool fused_ok = false;         // the window's tile fits in LDS: the fused kernel takes small batches and short chains
+    bool fused_c = false;          // … through its compile-time-l instance (dog_fused.hpp: l = 65, the default tracker's), whose tile layout is wider
     int hp_rows = HP_ROWS;         // RT rows (window columns) per column-pass workgroup: 16 (P = 13) or 8 (P = 7)
     int32_t *d_chain_tmp = nullptr; // [2][n_clips][2]: current guesses / step results of multi-clip chains
     int tp_ph1 = 13, tp_php = 7;   // outputs per task of the two-pass row / column pass (pick_twopass_p)
@@ -347,7 +349,7 @@ namespace {
 
 void pack_tile(const pdog_tracker *t, const uint8_t *frame, int64_t row_stride, int g1, int g2, uint8_t *dst, int pitch);
 typedef void (*fused_fn_t)(const FusedGeo, const f2 *, const f2 *);
-fused_fn_t fused_kernel_for(int L, bool resp);
+fused_fn_t fused_kernel_for(const pdog_tracker *t, bool resp);
 
 // LDS row pitches of the two-pass kernels: the sliding windows (and their one-block prefetch) of the last,
 // partly masked group of 13 outputs must stay inside the zero-padded row.  nout outputs, l taps.
@@ -434,6 +436,10 @@ int refine_slice_rows(int NA, int L, int cbw, size_t budget)
 {
     return (int)std::max<size_t>(8, std::min<size_t>((size_t)NA, budget / (size_t)refine_tile_pitch(cbw, L)));
 }
+size_t fused_tile_lds(const pdog_tracker *t)
+{
+    return t->fused_c ? fusedc_lds_bytes(t->n1, t->n2, t->L) : fused_lds_bytes(t->n1, t->n2, t->L);
+}
 void setup_refine_geometry(pdog_tracker *t)
 {
     const int NA = t->n1 + t->L - 1;
@@ -443,7 +449,9 @@ void setup_refine_geometry(pdog_tracker *t)
     // it with the whole pixel tile resident (a window whose tile fits as floats has room for it as bytes)
     t->fused_ref_cbw = 1;
     t->fused_ref_rows = NA;
-    const size_t have = fused_lds_bytes(t->n1, t->n2, t->L);
+    t->fused_c = fused_has_instance(t->L) && fusedc_lds_bytes(t->n1, t->n2, t->L) <= kMaxLds - 1024;
+    if (t->sw.no_fused_c) t->fused_c = false;
+    const size_t have = fused_tile_lds(t);
     for (int cbw = std::min(8, t->n2); cbw >= 1; --cbw)
         if (refine_lds_bytes(t->n1, t->L, cbw, NA) <= have) { t->fused_ref_cbw = cbw; break; }
     if (refine_lds_bytes(t->n1, t->L, 1, NA) > kMaxLds - 1024) t->fused_ref_rows = refine_slice_rows(NA, t->L, 1, 24576);
@@ -451,7 +459,7 @@ void setup_refine_geometry(pdog_tracker *t)
 // dynamic LDS of the fused kernel: its tile + RT, or the scratch of the refinement it may run in the same memory
 size_t fused_total_lds(const pdog_tracker *t)
 {
-    return std::max(fused_lds_bytes(t->n1, t->n2, t->L), refine_lds_bytes(t->n1, t->L, t->fused_ref_cbw, t->fused_ref_rows));
+    return std::max(fused_tile_lds(t), refine_lds_bytes(t->n1, t->L, t->fused_ref_cbw, t->fused_ref_rows));
 }
 
 int ensure_capacity(pdog_tracker *t, int n);
@@ -655,7 +663,7 @@ int choose_variant(pdog_tracker *t, int forced)
     t->fused_ok = fused_total_lds(t) <= kMaxLds - 1024 && t->n2 + t->L - 1 <= 4 * FUSED_NT && t->fw >= 4;
     if (t->fused_ok) {
         for (bool resp : {false, true}) {
-            if (int rc = raise_lds_limit((const void *)fused_kernel_for(t->L, resp), fused_total_lds(t))) return rc;
+            if (int rc = raise_lds_limit((const void *)fused_kernel_for(t, resp), fused_total_lds(t))) return rc;
         }
     }
     if (int rc = setup_tiled(t)) return rc;
@@ -729,9 +737,9 @@ int ensure_capacity(pdog_tracker *t, int n)
 }
 
 // fused-kernel instance (runtime kernel length)
-fused_fn_t fused_kernel_for(int L, bool resp)
+fused_fn_t fused_kernel_for(const pdog_tracker *t, bool resp)
 {
-    (void)L;
+    if (t->fused_c && t->L == 65) return resp ? (fused_fn_t)dog_fused_kernel<true, 0, 65> : (fused_fn_t)dog_fused_kernel<false, 0, 65>;
     return resp ? (fused_fn_t)dog_fused_kernel<true> : (fused_fn_t)dog_fused_kernel<false>;
 }
 
@@ -882,7 +890,7 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     g.L = t->L; g.fill = t->fill; g.nstrips = 1; g.n = n; g.nslots = 1; g.nblocks = n;
     fg.NA = t->n1 + t->L - 1;
     fg.TWin = t->n2 + t->L - 1;
-    fg.pitchA = fused_pitch_a(t->n2, t->L);
+    fg.pitchA = t->fused_c ? fusedc_pitch_a(t->n2, t->L) : fused_pitch_a(t->n2, t->L);
     fg.pitchV = fused_pitch_v(t->n1, t->L);
     fg.cshift = 0;
     while ((1 << fg.cshift) < (fg.TWin + 3) / 4) ++fg.cshift;
@@ -912,10 +920,10 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     g.ex = exact_ctl(t, kFamFused);
     const size_t lds = fused_total_lds(t);
     typedef fused_fn_t fused_fn;
-    fused_fn fn = fused_kernel_for(t->L, d_out_resp != nullptr);
+    fused_fn fn = fused_kernel_for(t, d_out_resp != nullptr);
 #ifdef PDOG_ABLATIONS
     if (d_out_resp && t->sw.fused_diag) { // phase stamps instead of the response (tools/fused_phases.py)
-        fn = (fused_fn)dog_fused_kernel<true, 1>;
+        fn = t->fused_c ? (fused_fn)dog_fused_kernel<true, 1, 65> : (fused_fn)dog_fused_kernel<true, 1>;
         if (int rc = raise_lds_limit((const void *)fn, lds)) return rc;
     }
 #endif
@@ -1547,7 +1555,13 @@ int pdog_set_tuning(pdog_tracker *t, const char *key, int value)
     else if (k == "no_fold") t->sw.no_fold = on;
     else if (k == "fold_always") t->sw.fold_always = on;
     else if (k == "fault_inject") t->sw.fault_inject = on;
-    else if (k == "no_tiled") {
+    else if (k == "no_fused_c") {
+        t->sw.no_fused_c = on;
+        setup_refine_geometry(t); // the tile layout, and with it the refinement's share of the kernel's LDS
+        if (t->fused_ok)
+            for (bool resp : {false, true})
+                if (int rc = raise_lds_limit((const void *)fused_kernel_for(t, resp), fused_total_lds(t))) return rc;
+    } else if (k == "no_tiled") {
         t->sw.no_tiled = on;
         if (int rc = setup_tiled(t)) return rc; // the tiled kernel's geometry is decided per tracker
     } else return fail(PDOG_E_ARG, "pdog_set_tuning: unknown key '" + k + "'");
