@@ -149,10 +149,15 @@ __device__ __forceinline__ int fusedc_row_base(int r, int pitch) { return r * pi
 // P outputs of one window column, l known: taps in blocks of 8 (one s_load_dwordx16 each, requested a block ahead), the window
 // entry e lives in register e mod (P − 1 + 16) — constant after unrolling, so nothing is ever shifted.
 template <int L, int P>
-__device__ __forceinline__ void fusedc_col_task(const f2 *a, tap_ptr taps, f2 (&acc)[P])
+__device__ __forceinline__ void fusedc_col_task(const f2 *a_, tap_ptr taps, f2 (&acc)[P])
 {
     constexpr int U = 8, NB = L / U, R = L - U * NB, W = P - 1 + 2 * U;
     static_assert(R >= 1 && R < U, "kernel lengths are odd");
+#ifdef FC_VOL
+    const volatile f2 *a = a_;
+#else
+    const f2 *a = a_;
+#endif
     f2 win[W];
 #pragma unroll
     for (int o = 0; o < P; ++o) acc[o] = f2{0.f, 0.f};
@@ -241,6 +246,11 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
             }
         };
         if (DIAG) { dc0 = __builtin_amdgcn_s_memtime(); dr0 = __builtin_amdgcn_s_memrealtime(); }
+        // chains (diagnostic build): every wave's own clock at four points of frame 20, behind the per-frame stamps
+        auto wstamp = [&](int i) {
+            if (DIAG && fg.chain_len > 20 && k == 20 && lane == 0 && b == 0)
+                g.resp[16 * fg.chain_len + 16 * i + wave] = (float)(__builtin_amdgcn_s_memtime() - dc0);
+        };
         // ---- per-window DC level (see dog_kernels.hpp) and staging.  Thread → (tile row tid >> cshift, 4-byte column
         // group tid & (2^cshift − 1)): one unaligned dword load per 4 pixels, no division.  The thread's DC sample
         // (one of the 32×32 grid of dc_sample_sum) and its first SU dwords are requested together — one memory round
@@ -316,6 +326,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
                 }
             }
         }
+        wstamp(3);
         __syncthreads();
         stamp(1);
         // ---- row pass → RT[x][a] ----
@@ -355,6 +366,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
             default: run(std::integral_constant<int, 8>{}); break;
             }
         }
+        wstamp(0);
         __syncthreads();
         stamp(2);
         // ---- column pass + peak ----
@@ -392,8 +404,10 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
             default: run(std::integral_constant<int, 8>{}); break;
             }
         }
+        wstamp(1);
         peak_wave_reduce(pk);
         if (lane == 0) { s_val[wave] = pk.best; s_idx[wave] = pk.idx; s_sec[wave] = pk.second; }
+        wstamp(2);
         stamp(5);
         __syncthreads();
         stamp(6);

@@ -81,34 +81,43 @@ __device__ __forceinline__ int wave_sum(int v)
     return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
-// The wave's peak, valid in EVERY lane on return.  Each step merges two disjoint sets of lanes, both partners compute the same
-// (symmetric) merge; the rows' totals are merged in row order from uniform registers.  width ≤ 16: only lanes 0 … 15 hold
-// peaks (the others hold peak_init values), one row is enough.
+// The wave's peak, uniform on return.  Three plain reductions instead of one reduction of (value, index, runner-up) triples —
+// on the latency path (one workgroup per window, its other waves waiting at a barrier) what costs is the LENGTH of the
+// dependent chain (≈9 cycles per instruction for a lone wave), and a triple merge is ≈15 dependent instructions per step:
+//   m      = max over lanes of best                                            (6 × v_max_f32 with a DPP operand)
+//   idx    = min over the lanes with best = m of their index                    (6 × v_min_i32: the FIRST maximum, findmax :59)
+//   second = max over lanes of (the lane holds the winning pixel ? its runner-up : its best)
+// A pixel that several lanes hold (overlapping strips: same index, bit-identical value) is excluded from `second` in all of
+// them — peak_merge's rule.  Steps: xor 1, xor 2, mirror in 8, mirror in 16 (every lane of a row then holds the row's result),
+// row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3: lane 63 holds the wave's.
+constexpr int DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143;
+template <typename F>
+__device__ __forceinline__ int wave_reduce_bits(int v, F op)
+{
+    v = op(v, dpp_i<DPP_XOR1>(v));
+    v = op(v, dpp_i<DPP_XOR2>(v));
+    v = op(v, dpp_i<DPP_HALF_MIRROR>(v));
+    v = op(v, dpp_i<DPP_MIRROR>(v));
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, DPP_BCAST15, 0xA, 0xF, false));
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, DPP_BCAST31, 0xC, 0xF, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+    return __builtin_bit_cast(float, wave_reduce_bits(__builtin_bit_cast(int, v), [](int a, int b) {
+        return __builtin_bit_cast(int, fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)));
+    }));
+}
+__device__ __forceinline__ int wave_min(int v) { return wave_reduce_bits(v, [](int a, int b) { return a < b ? a : b; }); }
 __device__ __forceinline__ void peak_wave_reduce(Peak &p, int width = 64)
 {
-    auto step = [&](auto ctrl) {
-        constexpr int C = decltype(ctrl)::value;
-        const float ov = dpp_f<C>(p.best);
-        const int oi = dpp_i<C>(p.idx);
-        const float os = dpp_f<C>(p.second);
-        peak_merge(p, ov, oi, os);
-    };
-    step(std::integral_constant<int, DPP_XOR1>{});
-    step(std::integral_constant<int, DPP_XOR2>{});
-    step(std::integral_constant<int, DPP_HALF_MIRROR>{});
-    step(std::integral_constant<int, DPP_MIRROR>{});
-    if (width > 16) {
-        Peak r;
-        r.best = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p.best), 0));
-        r.idx = __builtin_amdgcn_readlane(p.idx, 0);
-        r.second = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p.second), 0));
-#pragma unroll
-        for (int row = 1; row < 4; ++row)
-            peak_merge(r, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p.best), 16 * row)),
-                       __builtin_amdgcn_readlane(p.idx, 16 * row),
-                       __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p.second), 16 * row)));
-        p = r;
-    }
+    (void)width; // lanes that hold no peak hold peak_init's values
+    const float m = wave_max(p.best);
+    const int idx = wave_min(p.best == m ? p.idx : 0x7fffffff);
+    const float second = wave_max(p.idx == idx ? p.second : p.best);
+    p.best = m;
+    p.idx = idx;
+    p.second = second;
 }
 
 // Exact mode (dog_exact.hpp): a window whose two best FP32 responses lie within T = 2δ of each other is re-decided

@@ -13,6 +13,7 @@
 #include "dog_exact.hpp"
 #include "dog_tiled.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -925,6 +926,39 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     if (d_out_resp && t->sw.fused_diag) { // phase stamps instead of the response (tools/fused_phases.py)
         fn = t->fused_c ? (fused_fn)dog_fused_kernel<true, 1, 65> : (fused_fn)dog_fused_kernel<true, 1>;
         if (int rc = raise_lds_limit((const void *)fn, lds)) return rc;
+    }
+#endif
+#ifdef PDOG_ABLATIONS
+    if (!d_out_resp && t->sw.fused_diag && chain_len > 8) { // a chain's steady state: stamps of every frame, the median printed per phase
+        float *d_st = nullptr;
+        HIP_TRY(hipMalloc(&d_st, sizeof(float) * (16 * chain_len + 64)));
+        fg.g.resp = d_st;
+        fn = t->fused_c ? (fused_fn)dog_fused_kernel<true, 1, 65> : (fused_fn)dog_fused_kernel<true, 1>;
+        if (int rc = raise_lds_limit((const void *)fn, lds)) return rc;
+        hipLaunchKernelGGL(fn, dim3(n), dim3(FUSED_NT), lds, t->stream, fg, (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        std::vector<float> st(16 * (size_t)chain_len + 64);
+        HIP_TRY(hipMemcpy(st.data(), d_st, st.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipFree(d_st));
+        static const int order[7] = {0, 4, 1, 2, 5, 6, 3};
+        static const char *names[7] = {"samples", "barrier", "staged", "row pass", "col+peak(w0)", "barrier", "finalize"};
+        std::fprintf(stderr, "fused chain phases (median over frames 8.., 100 MHz ticks → us):");
+        int prev = -1;
+        for (int q = 0; q < 7; ++q) {
+            std::vector<float> d;
+            for (int k = 8; k < chain_len; ++k) d.push_back(st[16 * k + 8 + order[q]] - (prev < 0 ? 0.f : st[16 * k + 8 + prev]));
+            std::sort(d.begin(), d.end());
+            std::fprintf(stderr, " %s %.2f;", names[q], d[d.size() / 2] / 100.0);
+            prev = order[q];
+        }
+        std::fprintf(stderr, "\n");
+        static const char *wn[4] = {"row pass done", "col tasks done", "wave peak done", "staged"};
+        for (int i : {3, 0, 1, 2}) {
+            std::fprintf(stderr, "  frame 20, cycles since frame start, %s, waves 0-15:", wn[i]);
+            for (int w = 0; w < 16; ++w) std::fprintf(stderr, " %.0f", st[16 * (size_t)chain_len + 16 * i + w]);
+            std::fprintf(stderr, "\n");
+        }
+        return PDOG_OK;
     }
 #endif
     hipLaunchKernelGGL(fn, dim3(n), dim3(FUSED_NT), lds, t->stream, fg, (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
