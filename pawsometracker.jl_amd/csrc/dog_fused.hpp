@@ -148,44 +148,46 @@ __device__ __forceinline__ int fusedc_row_base(int r, int pitch) { return r * pi
 
 // P outputs of one window column, l known: taps in blocks of 8 (one s_load_dwordx16 each, requested a block ahead), the window
 // entry e lives in register e mod (P − 1 + 16) — constant after unrolling, so nothing is ever shifted.
-template <int L, int P>
-__device__ __forceinline__ void fusedc_col_task(const f2 *a_, tap_ptr taps, f2 (&acc)[P])
-{
-    constexpr int U = 8, NB = L / U, R = L - U * NB, W = P - 1 + 2 * U;
-    static_assert(R >= 1 && R < U, "kernel lengths are odd");
-#ifdef FC_VOL
-    const volatile f2 *a = a_;
-#else
-    const f2 *a = a_;
+#ifndef FC_PF
+#define FC_PF 1
 #endif
+#ifndef FC_ABL
+#define FC_ABL 0
+#endif
+template <int L, int P>
+__device__ __forceinline__ void fusedc_col_task(const f2 *a, tap_ptr taps, f2 (&acc)[P])
+{
+    constexpr int U = 8, NB = L / U, R = L - U * NB, PF = FC_PF, W = P - 1 + (PF + 1) * U;
+    static_assert(R >= 1 && R < U, "kernel lengths are odd");
     f2 win[W];
+    f2 tq[PF + 1][U];
 #pragma unroll
     for (int o = 0; o < P; ++o) acc[o] = f2{0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < P - 1 + U; ++e) win[e % W] = a[e];
-    f2 tn[U];
     tap_ptr tb = pin_taps(taps);
 #pragma unroll
-    for (int j = 0; j < U; ++j) tn[j] = tb[j];
+    for (int e = 0; e < P - 1 + PF * U; ++e) win[e % W] = a[e];
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+#pragma unroll
+        for (int j = 0; j < U; ++j) tq[d][j] = tb[U * d + j];
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
-        f2 t[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) t[j] = tn[j];
-        tb = pin_taps(tb);
-        const tap_ptr tnext = tb + U * (J + 1);
         constexpr int dummy = 0; (void)dummy;
-        const int nnew = (J + 1 < NB) ? U : R; // the entries and taps the next block (or the tail) needs
+        const int nb = J + PF;
+        const int nnew = nb < NB ? U : (nb == NB ? R : 0); // what block nb (or the tail) needs beyond what is there
+        tb = pin_taps(tb);
 #pragma unroll
         for (int j = 0; j < U; ++j)
             if (j < nnew) {
-                tn[j] = tnext[j];
-                win[(U * (J + 1) + P - 1 + j) % W] = a[U * (J + 1) + P - 1 + j];
+                if (!(FC_ABL & 1)) tq[nb % (PF + 1)][j] = tb[U * nb + j];
+                else tq[nb % (PF + 1)][j] = tq[(nb + PF) % (PF + 1)][j];
+                if (!(FC_ABL & 2)) win[(U * nb + P - 1 + j) % W] = a[U * nb + P - 1 + j];
+                else win[(U * nb + P - 1 + j) % W] = win[(U * nb + P - 1 + j + U) % W];
             }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[(U * J + u + o) % W], t[u], acc[o]);
+            for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[(U * J + u + o) % W], tq[J % (PF + 1)][u], acc[o]);
 #pragma unroll
         for (int o = 0; o < P; ++o) pin_acc(acc[o]);
         __builtin_amdgcn_sched_barrier(0);
@@ -193,7 +195,7 @@ __device__ __forceinline__ void fusedc_col_task(const f2 *a_, tap_ptr taps, f2 (
 #pragma unroll
     for (int u = 0; u < R; ++u)
 #pragma unroll
-        for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[(U * NB + u + o) % W], tn[u], acc[o]);
+        for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[(U * NB + u + o) % W], tq[NB % (PF + 1)][u], acc[o]);
 }
 
 // DIAG != 0 (diagnostic builds only): thread 0 of block 0 stamps the phase boundaries of every frame into g.resp
@@ -233,6 +235,12 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
     };
     zero_padding();
 
+    // Interior frames of the compile-time-l instances (the whole tile inside the frame — every frame of a clip but those at
+    // the border): a thread's addresses relative to the tile's origin never change, so a frame issues its five loads off one
+    // uniform base with no per-thread arithmetic, and unpacks with four conversions and a packed subtract per dword.
+    constexpr int SU = 4; // rows per thread and batch: the default 45×45 window (109 tile rows, 32 per pass) needs exactly 4
+    const int TW4 = (fg.TWin + 3) & ~3;
+
     int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
     for (int k = 0; k < fg.chain_len; ++k) {
         const long long fidx = fg.chain_len > 1 ? (long long)b * fg.chain_len + k : (g.frame_index ? g.frame_index[b] : b);
@@ -258,9 +266,54 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
         // Loads are unconditional at addresses clamped into the frame and the fill is selected afterwards (no branch
         // between two loads: all of a batch are in flight together); a clamped dword still holds every in-frame
         // byte its group needs, at a shifted position ----
-        {
-            constexpr int SU = 4; // rows per thread and batch: the default 45×45 window (109 tile rows, 32 per pass) needs exactly 4
-            const int q = tid & ((1 << fg.cshift) - 1), sr0 = tid >> fg.cshift, srstep = NT >> fg.cshift;
+        const bool interior = LT && ((NT >> fg.cshift) & 3) == 0 && ti0 >= 0 && ti0 + NA <= g.fh && wj0 >= 0 && wj0 + TW4 <= g.fw &&
+                              !(fg.dc_host >= 0 && fg.chain_len == 1);
+        // (the thread's offsets are derived again every frame from an opaque copy of its index: kept across the frame loop they
+        // take nine registers out of the row pass, which has none to spare)
+        int tid_f = tid;
+        asm volatile("" : "+v"(tid_f));
+        const int st_q = tid_f & ((1 << fg.cshift) - 1), st_r0 = tid_f >> fg.cshift, st_step = NT >> fg.cshift, st_c0 = 4 * st_q;
+        if (interior) {
+            const unsigned rs32 = (unsigned)g.row_stride;
+            const unsigned st_off0 = (unsigned)st_r0 * rs32 + (unsigned)st_c0;                          // bytes from the tile's first pixel
+            const unsigned st_soff = (unsigned)(((tid_f >> 5) * NA) >> 5) * rs32 + (unsigned)(((tid_f & 31) * fg.TWin) >> 5); // this thread's DC sample
+            const int st_lds0 = fusedc_row_base(st_r0, fg.pitchA) + st_c0;                               // floats; st_step is a multiple of 4: one skew for all of a thread's rows
+            const bool st_col = st_c0 < fg.TWin;
+            const uint8_t *__restrict__ base = frame + ((long long)ti0 * g.row_stride + wj0); // uniform
+            const int samp = base[st_soff];
+            uint32_t v[SU];
+            auto load_batch = [&](int it) {
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    // unconditional (a load inside a branch is waited for where the branch ends): idle threads read the tile's first dword
+                    const int r = st_r0 + (it * SU + u) * st_step;
+                    const unsigned off = (st_col && r < NA) ? st_off0 + (unsigned)((it * SU + u) * st_step) * rs32 : 0u;
+                    __builtin_memcpy(&v[u], base + off, 4);
+                }
+            };
+            load_batch(0);
+            const int wsum = wave_sum(samp);
+            if (lane == 0) s_sum[wave] = wsum;
+            stamp(0);
+            __syncthreads();
+            stamp(4);
+            int total = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) total += s_sum[w];
+            const float fdc = (float)dc_from_sum(total, g.fill);
+            for (int it = 0; st_r0 + it * SU * st_step < NA; ++it) {
+                if (it) load_batch(it);
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int r = st_r0 + (it * SU + u) * st_step;
+                    if (st_col && r < NA) {
+                        const f4 px = f4{(float)(v[u] & 0xffu), (float)((v[u] >> 8) & 0xffu), (float)((v[u] >> 16) & 0xffu), (float)(v[u] >> 24)};
+                        *reinterpret_cast<f4 *>(A + st_lds0 + (it * SU + u) * st_step * fg.pitchA) = px - fdc;
+                    }
+                }
+            }
+        } else {
+            const int q = st_q, sr0 = st_r0, srstep = st_step;
             const int c0 = 4 * q, gj0 = wj0 + c0, gj0c = min(max(gj0, 0), g.fw - 4);
             const uint8_t *colp = frame + gj0c;
             auto load_batch = [&](int r0, uint32_t (&v)[SU]) {
@@ -418,7 +471,9 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
             if (lane < NW) { pk.best = s_val[lane]; pk.idx = s_idx[lane]; pk.second = s_sec[lane]; }
             peak_wave_reduce(pk, NW);
             if (lane == 0) {
-                const int x = pk.idx / g.n1, y = pk.idx - x * g.n1;
+                // column = idx ÷ n1 by a float multiply (a window that fits LDS has < 2^15 pixels: idx + ½ stays further from a
+                // multiple of n1 than the rounding of the product) — an integer division is ≈40 dependent instructions here
+                const int x = (int)(((float)pk.idx + 0.5f) * (1.0f / (float)g.n1)), y = pk.idx - x * g.n1;
                 const int i = min(max(g1 - g.r1 + y, 1), g.fh);   // :60-61
                 const int j = min(max(g2 - g.r2 + x, 1), g.fw);
                 o_ij[0] = i;
