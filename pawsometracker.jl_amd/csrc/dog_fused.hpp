@@ -292,6 +292,10 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
                 }
             };
             load_batch(0);
+            // (Tried: the NEXT frame's tile at this frame's position requested behind these loads into a dummy LDS area
+            // (global_load_lds, no registers) so that its lines sit in this CU's vector cache a frame later — 8.9 against
+            // 8.5 µs per frame: the sample phase did not get shorter (it is address arithmetic and issue, not the memory
+            // round trip) and the workgroup barrier's fence waits for the extra loads.)
             const int wsum = wave_sum(samp);
             if (lane == 0) s_sum[wave] = wsum;
             stamp(0);
