@@ -97,11 +97,13 @@ def test_other_kernel_lengths(pt, golden, variant):
         t.close()
 
 
-def _batch(pt, frames, guesses, tw, ws, darker, fill, frame_index=None, want_resp=False, variant=None):
+def _batch(pt, frames, guesses, tw, ws, darker, fill, frame_index=None, want_resp=False, variant=None, tuning=None):
     import torch
     bt = pt.BatchTracker(frames.shape[1], frames.shape[2], tw, ws, darker, fill)
     if variant is not None:
         bt.set_variant(variant)
+    for key, val in (tuning or {}).items():
+        bt.set_tuning(key, val)
     bt.use_torch_stream()
     d_frames = torch.from_numpy(frames).cuda()
     d_guess = torch.from_numpy(np.ascontiguousarray(guesses, np.int32)).cuda()
@@ -603,6 +605,11 @@ def test_fused_kernel_batches_and_chains(pt, oracle):
         for b in range(0, n, max(1, n // 5)):
             _, r = oracle.detect(frames[b], fill, K, radii, guesses[b], want_resp=True)
             _check_resp(resp[b].T, r, f"fused {ws} {b}")
+        if tw == 25:
+            # l = 65 has a compile-time-length instance (the default above; interior and border tiles both occur in these
+            # batches); the runtime-length instance must give the same positions and bit-identical responses
+            generic, resp_g = _batch(pt, frames, guesses, tw, ws, True, fill, want_resp=True, variant=300, tuning={"no_fused_c": 1})
+            assert np.array_equal(generic, exp) and np.array_equal(resp_g, resp), (tw, ws)
     # chains: 5 clips x 30 frames, default 45x45 window; the automatic choice for few clips is the fused kernel
     h, w, tw, ws, nclips, nf = 160, 220, 25, (45, 45), 5, 30
     clips, starts, refs = [], [], []
@@ -623,8 +630,10 @@ def test_fused_kernel_batches_and_chains(pt, oracle):
     bt = pt.BatchTracker(h, w, tw, ws, True, fill)
     got = bt.detect_chains(torch.from_numpy(np.stack(clips)).cuda(), torch.tensor(starts, dtype=torch.int32).cuda()).cpu().numpy()
     single = bt.detect_chain(torch.from_numpy(clips[2]).cuda(), starts[2]).cpu().numpy()
+    bt.set_tuning("no_fused_c", 1)
+    got_g = bt.detect_chains(torch.from_numpy(np.stack(clips)).cuda(), torch.tensor(starts, dtype=torch.int32).cuda()).cpu().numpy()
     bt.close()
-    assert np.array_equal(got, np.stack(refs)) and np.array_equal(single, refs[2])
+    assert np.array_equal(got, np.stack(refs)) and np.array_equal(single, refs[2]) and np.array_equal(got_g, got)
 
 
 def test_identical_targets_tie_goes_to_the_first_in_column_major_order(pt, oracle):
