@@ -47,16 +47,17 @@ struct TiledGeo {
 
 constexpr int TILED_SLOT_CAP = 256; // sub-windows per window the combining wave handles (4 per lane)
 
-template <bool RESP>
+// LT > 0: the compile-time-l tasks and tile layout of dog_fused.hpp (fusedc_*), same values bit for bit.
+template <bool RESP, int LT = 0>
 __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, const f2 *__restrict__ taps_row,
                                                              const f2 *__restrict__ taps_col)
 {
     const LaunchGeo &g = tg.g;
     constexpr int NT = FUSED_NT, NW = NT / 64, U = FUSED_U;
-    const int L = g.L, hw = L >> 1;
+    const int L = LT ? LT : g.L, hw = L >> 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *A = reinterpret_cast<float *>(smem);
-    f2 *Vs = reinterpret_cast<f2 *>(smem + fused_a_bytes(tg.sn1, tg.sn2, L));
+    f2 *Vs = reinterpret_cast<f2 *>(smem + (LT ? fusedc_a_bytes(tg.sn1, tg.sn2, L) : fused_a_bytes(tg.sn1, tg.sn2, L)));
     __shared__ int s_sum[NW];
     __shared__ float s_val[NW], s_sec[NW];
     __shared__ int s_idx[NW];
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
 
     // tile columns ≥ TWs and RT columns ≥ NAs are only read by the sliding windows of masked outputs: zero once (and after a refinement)
     auto zero_padding = [&]() {
+        if (LT) return; // (the compile-time-l tasks read unstaged entries only into masked outputs)
         for (int r = wave; r < NAs; r += NW)
             for (int c = TWs + lane; c < tg.pitchA; c += 64) A[r * tg.pitchA + c] = 0.f;
         for (int x = wave; x < m2; x += NW)
@@ -127,12 +129,30 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
                 for (int w = 0; w < NW; ++w) total += s_sum[w];
                 dc = dc_from_sum(total, g.fill);
             }
+            const bool colin = gj0 >= 0 && gj0 + 4 <= g.fw;
+            const float fdc = (float)dc;
             for (int r0 = sr0; r0 < NAs; r0 += srstep * SU) {
                 if (r0 != sr0) load_batch(r0, v);
 #pragma unroll
                 for (int u = 0; u < SU; ++u) {
                     const int r = r0 + u * srstep, gi = ti0 + r;
                     const bool rowok = gi >= 0 && gi < g.fh;
+                    if (LT) { // four pixels → one 16-byte store (dog_fused.hpp)
+                        if (r < NAs && c0 < TWs) {
+                            f4 px;
+                            if (rowok && colin) {
+                                px = f4{(float)(v[u] & 0xffu), (float)((v[u] >> 8) & 0xffu), (float)((v[u] >> 16) & 0xffu), (float)(v[u] >> 24)};
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const int gj = gj0 + i;
+                                    px[i] = (float)((rowok && gj >= 0 && gj < g.fw) ? (int)((v[u] >> (8 * ((gj - gj0c) & 3))) & 0xffu) : g.fill);
+                                }
+                            }
+                            *reinterpret_cast<f4 *>(A + fusedc_row_base(r, tg.pitchA) + c0) = px - fdc;
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int gj = gj0 + i;
@@ -144,7 +164,20 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
         }
         __syncthreads();
         // ---- row pass → RT[x][a] ----
-        {
+        if constexpr (LT > 0) {
+            const int ngx = (m2 + 7) >> 3, ntask = NAs * ngx;
+            const float inv = 1.0f / (float)ngx;
+            for (int task = tid; task < ntask; task += NT) {
+                const int a = (int)(((float)task + 0.5f) * inv), gx = task - a * ngx, xb = 8 * gx;
+                f2 acc[ROLL_P];
+#pragma unroll
+                for (int o = 0; o < ROLL_P; ++o) acc[o] = f2{0.f, 0.f};
+                roll_row_pass<LT>(acc, A + fusedc_row_base(a, tg.pitchA) + xb, trow);
+#pragma unroll
+                for (int o = 0; o < ROLL_P; ++o)
+                    if (xb + o < m2) Vs[(xb + o) * tg.pitchV + a] = acc[o];
+            }
+        } else {
             const int ngx = (m2 + tg.pr - 1) / tg.pr, ntask = NAs * ngx;
             auto run = [&](auto Pc) {
                 constexpr int PR = decltype(Pc)::value;
@@ -173,10 +206,14 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
             const int ngy = (m1 + tg.pc - 1) / tg.pc, ntask = m2 * ngy;
             auto run = [&](auto Pc) {
                 constexpr int PC = decltype(Pc)::value;
+                const float inv = 1.0f / (float)m2;
                 for (int task = tid; task < ntask; task += NT) {
-                    const int gy = task / m2, x = task - gy * m2, yb = gy * PC;
+                    const int gy = LT ? (int)(((float)task + 0.5f) * inv) : task / m2, x = task - gy * m2, yb = gy * PC;
                     f2 acc[PC];
-                    fused_col_task<PC, U>(Vs + x * tg.pitchV + yb, L, tcol, acc);
+                    if constexpr (LT > 0)
+                        fusedc_col_task<LT, PC>(Vs + x * tg.pitchV + yb, tcol, acc);
+                    else
+                        fused_col_task<PC, U>(Vs + x * tg.pitchV + yb, L, tcol, acc);
 #pragma unroll
                     for (int o = 0; o < PC; ++o) {
                         const int y = yb + o;

@@ -283,6 +283,7 @@ struct pdog_tracker {
     int tiled_sn1 = 0, tiled_sn2 = 0, tiled_ns1 = 0, tiled_ns2 = 0, tiled_pr = 0, tiled_pc = 0, tiled_cshift = 0;
     int tiled_ref_cbw = 1, tiled_ref_rows = 8, tiled_resident = 0; // refinement scratch geometry; workgroups the device keeps resident
     size_t tiled_lds = 0;
+    bool tiled_c = false;          // the tiled kernel's compile-time-l instance (l = 65) and tile layout
     int *d_tiled_ctl = nullptr;    // [cap][4]: current guess (2), partial arrivals, frame flag
     int tiled_ctl_cap = 0;
     int chain_tmp_cap = 0;
@@ -482,6 +483,11 @@ int pick_outputs_per_task(int lines, int nout, std::initializer_list<int> ps, do
 
 // Tiled kernel (dog_tiled.hpp): windows too large for the fused kernel, cut into sub-windows of ≈48 rows/columns (a
 // 257×257 window: 6×6 of 43×43, each a tile of 107×107 like the default 45×45 window of the fused kernel).
+const void *tiled_kernel_for(const pdog_tracker *t, bool resp)
+{
+    if (t->tiled_c && t->L == 65) return resp ? (const void *)dog_tiled_kernel<true, 65> : (const void *)dog_tiled_kernel<false, 65>;
+    return resp ? (const void *)dog_tiled_kernel<true> : (const void *)dog_tiled_kernel<false>;
+}
 int setup_tiled(pdog_tracker *t)
 {
     t->tiled_ok = false;
@@ -493,6 +499,7 @@ int setup_tiled(pdog_tracker *t)
     size_t need = 0;
     bool found = false;
     const int user = t->sw.tiled_sub;
+    t->tiled_c = fused_has_instance(t->L) && !t->sw.no_fused_c;
     for (int target : {32, 40, 48, 56, 64, 24, 16}) {
         if (user) target = user;
         ns1 = (t->n1 + target - 1) / target;
@@ -501,7 +508,7 @@ int setup_tiled(pdog_tracker *t)
         sn2 = (t->n2 + ns2 - 1) / ns2;
         ns1 = (t->n1 + sn1 - 1) / sn1;
         ns2 = (t->n2 + sn2 - 1) / sn2;
-        need = fused_lds_bytes(sn1, sn2, t->L);
+        need = t->tiled_c ? fusedc_lds_bytes(sn1, sn2, t->L) : fused_lds_bytes(sn1, sn2, t->L);
         const bool fits = need <= kMaxLds - 1024 && sn2 + t->L - 1 <= 4 * FUSED_NT && (long long)ns1 * ns2 <= (target >= 32 && !user ? 128 : TILED_SLOT_CAP);
         if (fits) { found = true; break; }
         if (user) break;
@@ -527,13 +534,12 @@ int setup_tiled(pdog_tracker *t)
     while ((1 << t->tiled_cshift) < (sn2 + t->L - 1 + 3) / 4) ++t->tiled_cshift;
     t->tiled_pr = pick_outputs_per_task(sn1 + t->L - 1, sn2, {3, 4, 5, 6, 8}, 2.0);
     t->tiled_pc = pick_outputs_per_task(sn2, sn1, {2, 3, 4, 6, 8}, 1.5);
-    for (const void *f : {(const void *)dog_tiled_kernel<false>, (const void *)dog_tiled_kernel<true>}) {
-        if (int rc = raise_lds_limit(f, base)) return rc;
-    }
+    for (bool resp : {false, true})
+        if (int rc = raise_lds_limit(tiled_kernel_for(t, resp), base)) return rc;
     int per_cu = 0, cus = 0, coop = 0;
     t->tiled_resident = 0; // chains need every workgroup of a clip resident at once: a cooperative launch, if the device has them
     if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, t->device) == hipSuccess && coop &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)dog_tiled_kernel<false>, FUSED_NT, base) == hipSuccess && per_cu >= 1 &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tiled_kernel_for(t, false), FUSED_NT, base) == hipSuccess && per_cu >= 1 &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) == hipSuccess)
         t->tiled_resident = per_cu * cus;
     t->tiled_ok = true;
@@ -580,7 +586,7 @@ int launch_tiled(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     tg.NA = t->n1 + t->L - 1;
     tg.TWin = t->n2 + t->L - 1;
     tg.sn1 = t->tiled_sn1; tg.sn2 = t->tiled_sn2; tg.ns1 = t->tiled_ns1; tg.ns2 = t->tiled_ns2;
-    tg.pitchA = fused_pitch_a(t->tiled_sn2, t->L);
+    tg.pitchA = t->tiled_c ? fusedc_pitch_a(t->tiled_sn2, t->L) : fused_pitch_a(t->tiled_sn2, t->L);
     tg.pitchV = fused_pitch_v(t->tiled_sn1, t->L);
     tg.cshift = t->tiled_cshift;
     tg.pr = t->tiled_pr;
@@ -598,17 +604,15 @@ int launch_tiled(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     tg.sync = reinterpret_cast<unsigned *>(t->d_tiled_ctl + 2 * (size_t)t->tiled_ctl_cap);
     tg.abort = reinterpret_cast<unsigned *>(t->d_tiled_ctl + 4 * (size_t)t->tiled_ctl_cap);
     tg.fault_inject = t->sw.fault_inject ? 1 : 0;
-    const void *fn = d_out_resp ? (const void *)dog_tiled_kernel<true> : (const void *)dog_tiled_kernel<false>;
+    const void *fn = tiled_kernel_for(t, d_out_resp != nullptr);
     const f2 *tr = t->d_taps_row, *tc = t->d_taps_col;
     if (chain_len > 1) {
         void *args[] = {(void *)&tg, (void *)&tr, (void *)&tc};
         const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(n * nsub), dim3(FUSED_NT), args, (unsigned)t->tiled_lds, t->stream);
         if (e != hipSuccess) { (void)hipGetLastError(); return PDOG_OK; } // refused: the caller's other paths
     } else {
-        if (d_out_resp)
-            hipLaunchKernelGGL(dog_tiled_kernel<true>, dim3(n * nsub), dim3(FUSED_NT), t->tiled_lds, t->stream, tg, tr, tc);
-        else
-            hipLaunchKernelGGL(dog_tiled_kernel<false>, dim3(n * nsub), dim3(FUSED_NT), t->tiled_lds, t->stream, tg, tr, tc);
+        typedef void (*tiled_fn_t)(const TiledGeo, const f2 *, const f2 *);
+        hipLaunchKernelGGL((tiled_fn_t)fn, dim3(n * nsub), dim3(FUSED_NT), t->tiled_lds, t->stream, tg, tr, tc);
         HIP_TRY(hipGetLastError());
     }
     *launched = true;
@@ -1595,6 +1599,7 @@ int pdog_set_tuning(pdog_tracker *t, const char *key, int value)
         if (t->fused_ok)
             for (bool resp : {false, true})
                 if (int rc = raise_lds_limit((const void *)fused_kernel_for(t, resp), fused_total_lds(t))) return rc;
+        if (int rc = setup_tiled(t)) return rc;
     } else if (k == "no_tiled") {
         t->sw.no_tiled = on;
         if (int rc = setup_tiled(t)) return rc; // the tiled kernel's geometry is decided per tracker

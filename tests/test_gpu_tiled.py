@@ -89,9 +89,10 @@ def test_chain_equals_oracle_chain_and_two_pass_launches(pt, oracle):
         want.append(g)
     d_f = torch.from_numpy(frames).cuda()
 
-    def chain(no_tiled=False):
+    def chain(no_tiled=False, generic=False):
         bt = pt.BatchTracker(h, w, tw, ws, True, FILL)
         bt.set_tuning("no_tiled", int(no_tiled))
+        bt.set_tuning("no_fused_c", int(generic))  # l = 65: the runtime-length instance instead of the compile-time-length one
         out = bt.detect_chain(d_f, (h // 2, w // 2))
         bt.sync()
         res = [tuple(r) for r in out.cpu().numpy().tolist()]
@@ -106,6 +107,8 @@ def test_chain_equals_oracle_chain_and_two_pass_launches(pt, oracle):
     assert tiled and res == want and prog == want
     res2, prog2, tiled2 = chain(no_tiled=True)
     assert not tiled2 and res2 == want and prog2 == want
+    res3, prog3, tiled3 = chain(generic=True)
+    assert tiled3 and res3 == want and prog3 == want
 
 
 def test_ties_across_sub_window_borders_and_refinement(pt, oracle):
