@@ -540,7 +540,8 @@ def main():
     if rank == 0:
         sharding = (f"frames x{world}, one process per GPU, gather int32[n,2] to rank 0" + ("" if backend == "nccl" else f" ({backend} rehearsal)")) \
             if world > 1 else "single GPU"
-        res = result_line(args, desc, world, dt, kern_ms, batch, info, bt.kernel_for_batch(batch), fh, fw, tw, sharding)
+        res = result_line(args, desc, world, dt, kern_ms, batch, info, bt.kernel_for_batch(batch), fh, fw, tw, sharding,
+                          traffic_key=(f"tw{args.target_width:g}" if args.target_width and args.workload == "cfg3" else None))
         on, thr, refined1 = bt.exact_stats()
         res["exact"] = {"on": on, "threshold_2delta": thr, "refined_windows_per_step": (refined1 - refined0) / args.steps,
                         "since_create": dict(zip(("windows", "column_blocks", "candidates", "sequential_chains"), bt.exact_detail())),
