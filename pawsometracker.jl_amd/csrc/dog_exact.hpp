@@ -789,6 +789,7 @@ struct FinishGeo {
     int32_t *out_ij;             // [n][2]
     int32_t *done_flag;          // NULL or host-coherent ticket word (see dog_fused.hpp): published with window 0's final answer
     int32_t done_value;
+    int seq_windows;             // windows of this tracker's batches BEFORE this one (cumulative, wraps): published beside the flag count they produced
 };
 
 constexpr int REFINE_NT = 256;
@@ -860,9 +861,11 @@ static __global__ __launch_bounds__(REFINE_NT) void dog_finish_kernel(const Fini
     // windows flagged so far (up to the batches before this one), where the host can see it without a copy or a wait: it switches
     // batches of hard windows to the response-map path (pawsome_dog.hip).  One plain store per batch — a system-scope
     // atomic per workgroup with flagged windows cost cfg5, where every window is flagged, 0.7 ms of PCIe atomics.
-    if (blockIdx.x == 0 && tid == 0 && g.ex.range_err)
+    if (blockIdx.x == 0 && tid == 0 && g.ex.range_err) {
         __hip_atomic_store(g.ex.range_err + 1, (int)__hip_atomic_load(g.ex.stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(g.ex.range_err + 2, fg.seq_windows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // … out of how many windows
+    }
     // the windows of this workgroup that need the refinement (rare), one after the other, all threads on each
     constexpr int SLOT_CAP = 128;
     __shared__ float s_pv[SLOT_CAP];

@@ -293,8 +293,8 @@ struct pdog_tracker {
     // exact mode on the batch kernels of short kernels (roll / ring): windows flagged per batch as the finishing kernel reports
     // them (h_pinned[6], cumulative); batches of HARD windows (noise only, ±1-level targets: every window flagged) switch to
     // the response-map refinement like the two-pass path — 81–206 ms per 4096 windows of 257×257 without it
-    unsigned flag_last = 0;
-    int flag_n_prev = 0, flag_calm = 0;
+    unsigned flag_last = 0, win_last = 0, win_launched = 0; // flagged / finished windows last seen (h_pinned[6], [7]); windows handed to finishing kernels so far
+    int flag_calm = 0;
     bool roll_map = false;
     float *d_map = nullptr; // exact mode on the two-pass path: the batch's FP32 responses, where the refinement finds its candidates
     size_t map_bytes = 0;
@@ -866,6 +866,8 @@ int launch_finish(pdog_tracker *t, const LaunchGeo &g, int slot_w, int slot_last
     fg.out_ij = d_out_ij;
     fg.done_flag = d_done_flag;
     fg.done_value = done_value;
+    fg.seq_windows = (int)t->win_launched;
+    t->win_launched += (unsigned)g.n;
     size_t lds = t->exact ? refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_rows) : 0;
     if (g.fold_r) { // the folded remainder column's R values, one slice per wave (a window each)
         lds = std::max(lds, (size_t)FINISH_WPB * (t->n1 + t->L - 1 + FOLD_GO) * sizeof(f2));
@@ -1131,21 +1133,24 @@ int launch_detect(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride
         return launch_finish(t, g, hr, 1 << 30, d_out_ij, nullptr, 0, false, t->exact ? map : nullptr, tg.vmax);
     }
     const int grid = round_up(g.nblocks, 8);
-    // Exact mode: a batch whose predecessors flagged more than 2 % of their windows writes its responses (the kernels'
-    // RESP instances) and the finishing kernel reads the candidates off that map instead of recomputing them per window;
-    // back to the plain instances after eight batches below 0.5 %.  The count arrives through host-coherent memory, so
-    // nothing here waits for the GPU; it may lag by the batches still in flight.
+    // Exact mode: a batch whose predecessors flagged more than 8 % of their windows writes its responses (the kernels'
+    // RESP instances: +15 % on the strips) and the finishing kernel reads the candidates off that map instead of recomputing
+    // them per window; back to the plain instances after eight observations below 2 %.  The finishing kernels publish the
+    // flagged count TOGETHER with the number of windows it came from, through host-coherent memory: nothing here waits for
+    // the GPU, and the rate is right however many batches are in flight (round 2 compared the count's increase with ONE
+    // batch's size: with three batches in flight 0.9 % looked like 2.7 % and one step in four paid for a map it did not need).
     const float *map = d_out_resp;
     if (t->exact && !t->exact_all) {
         const unsigned cur = (unsigned)__atomic_load_n(&t->h_pinned[6], __ATOMIC_ACQUIRE); // (the low 32 bits of a cumulative count: differences wrap correctly)
-        const long long delta = (long long)(unsigned)(cur - t->flag_last);
-        t->flag_last = cur;
-        if (t->flag_n_prev > 0) {
-            if (delta * 50 > t->flag_n_prev) { t->roll_map = true; t->flag_calm = 0; }
-            else if (delta * 200 < t->flag_n_prev) { if (++t->flag_calm >= 8) t->roll_map = false; }
+        const unsigned curw = (unsigned)__atomic_load_n(&t->h_pinned[7], __ATOMIC_ACQUIRE);
+        const long long delta = (long long)(unsigned)(cur - t->flag_last), dwin = (long long)(unsigned)(curw - t->win_last);
+        if (dwin > 0) {
+            t->flag_last = cur;
+            t->win_last = curw;
+            if (delta * 12 > dwin) { t->roll_map = true; t->flag_calm = 0; }
+            else if (delta * 50 < dwin) { if (++t->flag_calm >= 8) t->roll_map = false; }
             else t->flag_calm = 0;
         }
-        t->flag_n_prev = n;
         const size_t need = sizeof(float) * (size_t)n * t->n1 * t->n2;
         if (!map && t->roll_map && !t->sw.no_roll_map && need <= t->sw.map_cap) {
             if (t->map_bytes < need) {
