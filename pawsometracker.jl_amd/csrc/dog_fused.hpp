@@ -148,46 +148,37 @@ __device__ __forceinline__ int fusedc_row_base(int r, int pitch) { return r * pi
 
 // P outputs of one window column, l known: taps in blocks of 8 (one s_load_dwordx16 each, requested a block ahead), the window
 // entry e lives in register e mod (P − 1 + 16) — constant after unrolling, so nothing is ever shifted.
-#ifndef FC_PF
-#define FC_PF 1
-#endif
-#ifndef FC_ABL
-#define FC_ABL 0
-#endif
 template <int L, int P>
 __device__ __forceinline__ void fusedc_col_task(const f2 *a, tap_ptr taps, f2 (&acc)[P])
 {
-    constexpr int U = 8, NB = L / U, R = L - U * NB, PF = FC_PF, W = P - 1 + (PF + 1) * U;
+    // (a prefetch distance of two blocks measured equal to one; taps and window entries of block J + 1 are requested while
+    // block J's FMAs issue — the compiler sinks the requests below the wait for block J's own)
+    constexpr int U = 8, NB = L / U, R = L - U * NB, W = P - 1 + 2 * U;
     static_assert(R >= 1 && R < U, "kernel lengths are odd");
     f2 win[W];
-    f2 tq[PF + 1][U];
+    f2 tq[2][U];
 #pragma unroll
     for (int o = 0; o < P; ++o) acc[o] = f2{0.f, 0.f};
     tap_ptr tb = pin_taps(taps);
 #pragma unroll
-    for (int e = 0; e < P - 1 + PF * U; ++e) win[e % W] = a[e];
+    for (int e = 0; e < P - 1 + U; ++e) win[e % W] = a[e];
 #pragma unroll
-    for (int d = 0; d < PF; ++d)
-#pragma unroll
-        for (int j = 0; j < U; ++j) tq[d][j] = tb[U * d + j];
+    for (int j = 0; j < U; ++j) tq[0][j] = tb[j];
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
-        constexpr int dummy = 0; (void)dummy;
-        const int nb = J + PF;
-        const int nnew = nb < NB ? U : (nb == NB ? R : 0); // what block nb (or the tail) needs beyond what is there
+        const int nb = J + 1;
+        const int nnew = nb < NB ? U : R; // what block nb (or the tail of R taps) needs beyond what is there
         tb = pin_taps(tb);
 #pragma unroll
         for (int j = 0; j < U; ++j)
             if (j < nnew) {
-                if (!(FC_ABL & 1)) tq[nb % (PF + 1)][j] = tb[U * nb + j];
-                else tq[nb % (PF + 1)][j] = tq[(nb + PF) % (PF + 1)][j];
-                if (!(FC_ABL & 2)) win[(U * nb + P - 1 + j) % W] = a[U * nb + P - 1 + j];
-                else win[(U * nb + P - 1 + j) % W] = win[(U * nb + P - 1 + j + U) % W];
+                tq[nb & 1][j] = tb[U * nb + j];
+                win[(U * nb + P - 1 + j) % W] = a[U * nb + P - 1 + j];
             }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[(U * J + u + o) % W], tq[J % (PF + 1)][u], acc[o]);
+            for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[(U * J + u + o) % W], tq[J & 1][u], acc[o]);
 #pragma unroll
         for (int o = 0; o < P; ++o) pin_acc(acc[o]);
         __builtin_amdgcn_sched_barrier(0);
@@ -195,7 +186,7 @@ __device__ __forceinline__ void fusedc_col_task(const f2 *a, tap_ptr taps, f2 (&
 #pragma unroll
     for (int u = 0; u < R; ++u)
 #pragma unroll
-        for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[(U * NB + u + o) % W], tq[NB % (PF + 1)][u], acc[o]);
+        for (int o = 0; o < P; ++o) acc[o] = fma_pair(win[(U * NB + u + o) % W], tq[NB & 1][u], acc[o]);
 }
 
 // DIAG != 0 (diagnostic builds only): thread 0 of block 0 stamps the phase boundaries of every frame into g.resp
