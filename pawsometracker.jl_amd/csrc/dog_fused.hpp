@@ -140,7 +140,7 @@ __device__ __forceinline__ void fused_col_task(const f2 *a, int L, tap_ptr taps,
 // The tile then lives in the roll kernel's layout: rows on a pitch of whole bank rows, skewed by {0, 1, 8, 9} 16-byte slots
 // by (row & 3), so that the b128 reads of a lane group (rows r, r+1 × 8 output groups) are conflict free.  Same operation
 // order per output as the runtime-length tasks above: the two kernels' responses are bit-identical.
-__host__ __device__ constexpr bool fused_has_instance(int L) { return L == 65; }
+__host__ __device__ constexpr bool fused_has_instance(int L) { return L % 4 == 1 && L >= 29 && L <= 101; } // lat_lengths.def
 __host__ __device__ constexpr int fusedc_pitch_a(int n2, int L) { return (8 * ((n2 + 7) / 8) + L + 39 + 63) / 64 * 64; }
 __host__ __device__ constexpr size_t fusedc_a_bytes(int n1, int n2, int L) { return ((size_t)(n1 + L - 1) * fusedc_pitch_a(n2, L) + 64) * 4; }
 __host__ __device__ constexpr size_t fusedc_lds_bytes(int n1, int n2, int L) { return fusedc_a_bytes(n1, n2, L) + (size_t)n2 * fused_pitch_v(n1, L) * 8; }
@@ -533,9 +533,11 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
 }
 
 // frames finished so far, for paths whose own kernels do not publish it (see pdog_detect_chain_progress)
+#ifndef PDOG_ROLL_INST_ONLY
 static __global__ void dog_publish_kernel(int32_t *flag, int32_t value)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+#endif
 
 } // namespace pdog

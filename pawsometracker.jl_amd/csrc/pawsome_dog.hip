@@ -29,6 +29,17 @@
 
 using namespace pdog;
 
+// compile-time-length instances of the latency kernels: built in lat_inst.hip, one translation unit per length
+namespace pdog {
+#define PDOG_LAT_L(LT)                                                                                          \
+    extern template __global__ void dog_fused_kernel<false, 0, LT>(const FusedGeo, const f2 *, const f2 *);    \
+    extern template __global__ void dog_fused_kernel<true, 0, LT>(const FusedGeo, const f2 *, const f2 *);     \
+    extern template __global__ void dog_tiled_kernel<false, LT>(const TiledGeo, const f2 *, const f2 *);       \
+    extern template __global__ void dog_tiled_kernel<true, LT>(const TiledGeo, const f2 *, const f2 *);
+#include "lat_lengths.def"
+#undef PDOG_LAT_L
+} // namespace pdog
+
 // the roll kernels are instantiated in roll_inst.hip (one translation unit per set of lengths, built in parallel)
 namespace pdog {
 #define PDOG_ROLL_L(LT)                                                                                          \
@@ -485,7 +496,12 @@ int pick_outputs_per_task(int lines, int nout, std::initializer_list<int> ps, do
 // 257×257 window: 6×6 of 43×43, each a tile of 107×107 like the default 45×45 window of the fused kernel).
 const void *tiled_kernel_for(const pdog_tracker *t, bool resp)
 {
-    if (t->tiled_c && t->L == 65) return resp ? (const void *)dog_tiled_kernel<true, 65> : (const void *)dog_tiled_kernel<false, 65>;
+    if (t->tiled_c) switch (t->L) {
+#define PDOG_LAT_L(LT) case LT: return resp ? (const void *)dog_tiled_kernel<true, LT> : (const void *)dog_tiled_kernel<false, LT>;
+#include "lat_lengths.def"
+#undef PDOG_LAT_L
+        default: break;
+    }
     return resp ? (const void *)dog_tiled_kernel<true> : (const void *)dog_tiled_kernel<false>;
 }
 int setup_tiled(pdog_tracker *t)
@@ -744,7 +760,12 @@ int ensure_capacity(pdog_tracker *t, int n)
 // fused-kernel instance (runtime kernel length)
 fused_fn_t fused_kernel_for(const pdog_tracker *t, bool resp)
 {
-    if (t->fused_c && t->L == 65) return resp ? (fused_fn_t)dog_fused_kernel<true, 0, 65> : (fused_fn_t)dog_fused_kernel<false, 0, 65>;
+    if (t->fused_c) switch (t->L) {
+#define PDOG_LAT_L(LT) case LT: return resp ? (fused_fn_t)dog_fused_kernel<true, 0, LT> : (fused_fn_t)dog_fused_kernel<false, 0, LT>;
+#include "lat_lengths.def"
+#undef PDOG_LAT_L
+        default: break;
+    }
     return resp ? (fused_fn_t)dog_fused_kernel<true> : (fused_fn_t)dog_fused_kernel<false>;
 }
 
@@ -930,7 +951,7 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     fused_fn fn = fused_kernel_for(t, d_out_resp != nullptr);
 #ifdef PDOG_ABLATIONS
     if (d_out_resp && t->sw.fused_diag) { // phase stamps instead of the response (tools/fused_phases.py)
-        fn = t->fused_c ? (fused_fn)dog_fused_kernel<true, 1, 65> : (fused_fn)dog_fused_kernel<true, 1>;
+        fn = (t->fused_c && t->L == 65) ? (fused_fn)dog_fused_kernel<true, 1, 65> : (fused_fn)dog_fused_kernel<true, 1>;
         if (int rc = raise_lds_limit((const void *)fn, lds)) return rc;
     }
 #endif
@@ -939,7 +960,7 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
         float *d_st = nullptr;
         HIP_TRY(hipMalloc(&d_st, sizeof(float) * (16 * chain_len + 64)));
         fg.g.resp = d_st;
-        fn = t->fused_c ? (fused_fn)dog_fused_kernel<true, 1, 65> : (fused_fn)dog_fused_kernel<true, 1>;
+        fn = (t->fused_c && t->L == 65) ? (fused_fn)dog_fused_kernel<true, 1, 65> : (fused_fn)dog_fused_kernel<true, 1>;
         if (int rc = raise_lds_limit((const void *)fn, lds)) return rc;
         hipLaunchKernelGGL(fn, dim3(n), dim3(FUSED_NT), lds, t->stream, fg, (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
         HIP_TRY(hipStreamSynchronize(t->stream));
