@@ -144,7 +144,7 @@ int pdog_set_exact(pdog_tracker *t, int on);
  *   "host_sync"    … reads in place but waits with a stream synchronise instead of the ticket
  *   "twopass_4l"   the two-pass kernels always in their four-launch form
  *   "no_tiled"     single large windows on the two-pass launches instead of the tiled kernel
- *   "no_fused_c"   the one-workgroup kernels' runtime-length instances also where a compile-time-length one exists (l = 65)
+ *   "no_fused_c"   the one-workgroup kernels' runtime-length instances also where a compile-time-length one exists (l = 29 … 101)
  *   "fault_inject" tests: one workgroup of a tiled chain skips an arrival (the bounded device-side waits must give up)
  *   "no_roll_map"  hard batches keep recomputing their refinement candidates
  *   "no_fold" / "fold_always"  a single remainder column always / never goes to the remainder-column kernel
