@@ -278,7 +278,8 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
                 for (int u = 0; u < SU; ++u) {
                     // unconditional (a load inside a branch is waited for where the branch ends): idle threads read the tile's first dword
                     const int r = st_r0 + (it * SU + u) * st_step;
-                    const unsigned off = (st_col && r < NA) ? st_off0 + (unsigned)((it * SU + u) * st_step) * rs32 : 0u;
+                    unsigned off = (st_col && r < NA) ? st_off0 + (unsigned)((it * SU + u) * st_step) * rs32 : 0u;
+                    asm volatile("" : "+v"(off)); // (opaque: the compiler otherwise turns the select into a branch around a second, uniform-address load and waits for it with vmcnt(0))
                     __builtin_memcpy(&v[u], base + off, 4);
                 }
             };
