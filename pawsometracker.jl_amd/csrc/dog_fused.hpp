@@ -144,6 +144,13 @@ __host__ __device__ constexpr bool fused_has_instance(int L) { return L % 4 == 1
 __host__ __device__ constexpr int fusedc_pitch_a(int n2, int L) { return (8 * ((n2 + 7) / 8) + L + 39 + 63) / 64 * 64; }
 __host__ __device__ constexpr size_t fusedc_a_bytes(int n1, int n2, int L) { return ((size_t)(n1 + L - 1) * fusedc_pitch_a(n2, L) + 64) * 4; }
 __host__ __device__ constexpr size_t fusedc_lds_bytes(int n1, int n2, int L) { return fusedc_a_bytes(n1, n2, L) + (size_t)n2 * fused_pitch_v(n1, L) * 8; }
+// outputs per row-pass task of the compile-time-l instances: 8, or 4 where that loads the busiest SIMD less (waves of 64 tasks,
+// four SIMDs; ≈51 / ≈53 instructions per output)
+__host__ __device__ constexpr int fusedc_row_outputs(int NA, int n2)
+{
+    const int w8 = (NA * ((n2 + 7) / 8) + 63) / 64, w4 = (NA * ((n2 + 3) / 4) + 63) / 64;
+    return ((w4 + 3) / 4) * 212 < ((w8 + 3) / 4) * 408 ? 4 : 8;
+}
 __device__ __forceinline__ int fusedc_row_base(int r, int pitch) { return r * pitch + 4 * ((r & 1) + ((r & 2) ? 8 : 0)); }
 
 // P outputs of one window column, l known: taps in blocks of 8 (one s_load_dwordx16 each, requested a block ahead), the window
@@ -380,20 +387,26 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
         stamp(1);
         // ---- row pass → RT[x][a] ----
         if constexpr (LT > 0) {
-            // task = (tile row a, group of 8 outputs), dense over the threads; the division by the group count is a float
-            // multiply (task + ½ never comes within 1/(2·ngx) of a multiple of ngx: exact for every task count that fits LDS)
-            const int ngx = (g.n2 + 7) >> 3, ntask = NA * ngx;
-            const float inv = 1.0f / (float)ngx;
-            for (int task = tid; task < ntask; task += NT) {
-                const int a = (int)(((float)task + 0.5f) * inv), gx = task - a * ngx, xb = 8 * gx;
-                f2 acc[ROLL_P];
+            // task = (tile row a, group of PR = 8 or 4 outputs), dense over the threads; the division by the group count is a float
+            // multiply (task + ½ never comes within 1/(2·ngx) of a multiple of ngx: exact for every task count that fits LDS).
+            // PR is the host's choice (fusedc_row_outputs): 4 where tasks of 8 would leave most waves without one.
+            auto run = [&](auto Pc) {
+                constexpr int PR = decltype(Pc)::value;
+                const int ngx = (g.n2 + PR - 1) / PR, ntask = NA * ngx;
+                const float inv = 1.0f / (float)ngx;
+                for (int task = tid; task < ntask; task += NT) {
+                    const int a = (int)(((float)task + 0.5f) * inv), gx = task - a * ngx, xb = PR * gx;
+                    f2 acc[PR];
 #pragma unroll
-                for (int o = 0; o < ROLL_P; ++o) acc[o] = f2{0.f, 0.f};
-                roll_row_pass<LT>(acc, A + fusedc_row_base(a, fg.pitchA) + xb, trow);
+                    for (int o = 0; o < PR; ++o) acc[o] = f2{0.f, 0.f};
+                    roll_row_pass<LT, PR>(acc, A + fusedc_row_base(a, fg.pitchA) + xb, trow);
 #pragma unroll
-                for (int o = 0; o < ROLL_P; ++o)
-                    if (xb + o < g.n2) Vs[(xb + o) * fg.pitchV + a] = acc[o];
-            }
+                    for (int o = 0; o < PR; ++o)
+                        if (xb + o < g.n2) Vs[(xb + o) * fg.pitchV + a] = acc[o];
+                }
+            };
+            if (fg.pr == 4) run(std::integral_constant<int, 4>{});
+            else run(std::integral_constant<int, 8>{});
         } else {
             const int ngx = (g.n2 + fg.pr - 1) / fg.pr, ntask = NA * ngx;
             auto run = [&](auto Pc) {

@@ -93,17 +93,22 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // window 64·k + 1 columns wide (257, 513, …), the column round 2 gave to dog_thin_kernel.  The odd taps already hold its
 // pair sums (the outer half of their fifth v_pk_add_f32), the even taps add one: +49 packed instructions per sub-chunk
 // in the one strip per window that folds, instead of a second kernel re-reading a 65-column patch per window.
+// NOUT = 4: four outputs per lane (pairs (0,1) (2,3) / (−1,0) (1,2) (3,4), two-quad windows) for the latency kernels' small tiles,
+// where tasks of 8 outputs leave most of a 1024-thread workgroup without one (dog_tiled.hpp).
 template <int L, int NOUT = ROLL_P>
-__device__ __forceinline__ void roll_row_pass(f2 (&acc)[NOUT == ROLL_P ? ROLL_P : ROLL_P + 2], const float *a, tap_ptr taps)
+__device__ __forceinline__ void roll_row_pass(f2 (&acc)[NOUT == 9 ? ROLL_P + 2 : NOUT], const float *a, tap_ptr taps)
 {
-    constexpr int P = ROLL_P, H = L / 2, U = 4, NB = (H + U - 1) / U, HQ = H / 2;
-    constexpr int NHI = (NOUT == P) ? 3 : 4, ME = (NOUT == P) ? 4 : 5; // hi-window quads; pair sums per even tap
-    static_assert(P == 8 && (NOUT == 8 || NOUT == 9) && H % 2 == 0, "the pairing below is written for 8 (+1) outputs and L = 4m + 1");
+    constexpr int P = (NOUT == 9) ? 8 : NOUT, H = L / 2, U = 4, NB = (H + U - 1) / U, HQ = H / 2;
+    constexpr int NLO = P / 4 + 1;                       // lo-window quads: pairs 2J … 2J + P/2 + 1
+    constexpr int NHI = NLO + (NOUT == 9 ? 1 : 0);       // hi-window quads
+    constexpr int ME = P / 2 + (NOUT == 9 ? 1 : 0);      // pair sums per even tap
+    constexpr int MO = P / 2 + 1;                        // pair sums per odd tap
+    static_assert((P == 8 || P == 4) && (NOUT == 4 || NOUT == 8 || NOUT == 9) && H % 2 == 0, "the pairing below is written for 4 or 8 (+1) outputs and L = 4m + 1");
     auto quad = [&](int q) { return *reinterpret_cast<const f4 *>(a + 4 * q); };
     auto half = [](const f4 &v, int h) { return h ? __builtin_shufflevector(v, v, 2, 3) : __builtin_shufflevector(v, v, 0, 1); };
-    f4 lw[3], hw[NHI]; // quads J … J+2 and HQ−J−1 … HQ−J−2+NHI
+    f4 lw[NLO], hw[NHI]; // quads J … J+NLO−1 and HQ−J−1 … HQ−J−2+NHI
 #pragma unroll
-    for (int j = 0; j < 3; ++j) lw[j] = quad(j);
+    for (int j = 0; j < NLO; ++j) lw[j] = quad(j);
 #pragma unroll
     for (int j = 0; j < NHI; ++j) hw[j] = quad(HQ - 1 + j);
     f2 tn[U];
@@ -118,13 +123,13 @@ __device__ __forceinline__ void roll_row_pass(f2 (&acc)[NOUT == ROLL_P ? ROLL_P 
         f2 t[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) t[j] = tn[j];
-        f4 nl = lw[2], nh = hw[0];
+        f4 nl = lw[NLO - 1], nh = hw[0];
         tb = pin_taps(tb);
         const tap_ptr tnext = tb + (more ? k0 + U : H);
         if (more) {
 #pragma unroll
             for (int j = 0; j < U; ++j) tn[j] = tnext[j]; // may run past tap H−1 on the last full load: those entries are never used
-            nl = quad(J + 3);      // new upper quad of the next lo window
+            nl = quad(J + NLO);    // new upper quad of the next lo window
             nh = quad(HQ - J - 2); // new lower quad of the next hi window
         } else {
             tn[0] = tnext[0]; // centre tap
@@ -140,30 +145,32 @@ __device__ __forceinline__ void roll_row_pass(f2 (&acc)[NOUT == ROLL_P ? ROLL_P 
                     for (int m = 0; m < ME; ++m) {
                         const f2 s2 = LO(k / 2 + m) + HI(H - k / 2 + m);
                         acc[2 * m] = fma_bcast(s2.x, t[u], acc[2 * m]);
-                        if (m < 4) acc[2 * m + 1] = fma_bcast(s2.y, t[u], acc[2 * m + 1]);
+                        if (m < P / 2) acc[2 * m + 1] = fma_bcast(s2.y, t[u], acc[2 * m + 1]);
                     }
                 } else {
 #pragma unroll
-                    for (int m = 0; m < 5; ++m) {
+                    for (int m = 0; m < MO; ++m) {
                         const f2 s2 = LO((k - 1) / 2 + m) + HI(H - (k + 1) / 2 + m);
                         if (m >= 1) acc[2 * m - 1] = fma_bcast(s2.x, t[u], acc[2 * m - 1]);
-                        if (m <= 3 || NOUT == 9) acc[2 * m] = fma_bcast(s2.y, t[u], acc[2 * m]);
+                        if (m < P / 2 || NOUT == 9) acc[2 * m] = fma_bcast(s2.y, t[u], acc[2 * m]);
                     }
                 }
             }
         }
         if (more) {
-            lw[0] = lw[1]; lw[1] = lw[2]; lw[2] = nl;
+#pragma unroll
+            for (int j = 0; j + 1 < NLO; ++j) lw[j] = lw[j + 1];
+            lw[NLO - 1] = nl;
 #pragma unroll
             for (int j = NHI - 1; j > 0; --j) hw[j] = hw[j - 1];
             hw[0] = nh;
         } else {
-            // centre tap: a[o + H], the pairs E[HQ … HQ+3 (+1)] — inside the last hi window whatever H mod 4 is
+            // centre tap: a[o + H], the pairs E[HQ … HQ + P/2 − 1 (+1)] — inside the last hi window whatever H mod 4 is
 #pragma unroll
             for (int m = 0; m < ME; ++m) {
                 const f2 c2 = HI(HQ + m);
                 acc[2 * m] = fma_bcast(c2.x, tn[0], acc[2 * m]);
-                if (m < 4) acc[2 * m + 1] = fma_bcast(c2.y, tn[0], acc[2 * m + 1]);
+                if (m < P / 2) acc[2 * m + 1] = fma_bcast(c2.y, tn[0], acc[2 * m + 1]);
             }
         }
 #pragma unroll

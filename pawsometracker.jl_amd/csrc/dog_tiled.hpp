@@ -165,18 +165,26 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
         __syncthreads();
         // ---- row pass → RT[x][a] ----
         if constexpr (LT > 0) {
-            const int ngx = (m2 + 7) >> 3, ntask = NAs * ngx;
-            const float inv = 1.0f / (float)ngx;
-            for (int task = tid; task < ntask; task += NT) {
-                const int a = (int)(((float)task + 0.5f) * inv), gx = task - a * ngx, xb = 8 * gx;
-                f2 acc[ROLL_P];
+            // task = (tile row a, group of PR = 8 or 4 outputs), dense over the threads; the division by the group count is a float
+            // multiply (task + ½ never comes within 1/(2·ngx) of a multiple of ngx: exact for every task count that fits LDS).
+            // PR is the host's choice (fusedc_row_outputs): 4 where tasks of 8 would leave most waves without one.
+            auto run = [&](auto Pc) {
+                constexpr int PR = decltype(Pc)::value;
+                const int ngx = (m2 + PR - 1) / PR, ntask = NAs * ngx;
+                const float inv = 1.0f / (float)ngx;
+                for (int task = tid; task < ntask; task += NT) {
+                    const int a = (int)(((float)task + 0.5f) * inv), gx = task - a * ngx, xb = PR * gx;
+                    f2 acc[PR];
 #pragma unroll
-                for (int o = 0; o < ROLL_P; ++o) acc[o] = f2{0.f, 0.f};
-                roll_row_pass<LT>(acc, A + fusedc_row_base(a, tg.pitchA) + xb, trow);
+                    for (int o = 0; o < PR; ++o) acc[o] = f2{0.f, 0.f};
+                    roll_row_pass<LT, PR>(acc, A + fusedc_row_base(a, tg.pitchA) + xb, trow);
 #pragma unroll
-                for (int o = 0; o < ROLL_P; ++o)
-                    if (xb + o < m2) Vs[(xb + o) * tg.pitchV + a] = acc[o];
-            }
+                    for (int o = 0; o < PR; ++o)
+                        if (xb + o < m2) Vs[(xb + o) * tg.pitchV + a] = acc[o];
+                }
+            };
+            if (tg.pr == 4) run(std::integral_constant<int, 4>{});
+            else run(std::integral_constant<int, 8>{});
         } else {
             const int ngx = (m2 + tg.pr - 1) / tg.pr, ntask = NAs * ngx;
             auto run = [&](auto Pc) {

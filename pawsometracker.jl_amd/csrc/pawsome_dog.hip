@@ -548,7 +548,7 @@ int setup_tiled(pdog_tracker *t)
     t->tiled_lds = base;
     t->tiled_cshift = 0;
     while ((1 << t->tiled_cshift) < (sn2 + t->L - 1 + 3) / 4) ++t->tiled_cshift;
-    t->tiled_pr = pick_outputs_per_task(sn1 + t->L - 1, sn2, {3, 4, 5, 6, 8}, 2.0);
+    t->tiled_pr = t->tiled_c ? fusedc_row_outputs(sn1 + t->L - 1, sn2) : pick_outputs_per_task(sn1 + t->L - 1, sn2, {3, 4, 5, 6, 8}, 2.0);
     t->tiled_pc = pick_outputs_per_task(sn2, sn1, {2, 3, 4, 6, 8}, 1.5);
     for (bool resp : {false, true})
         if (int rc = raise_lds_limit(tiled_kernel_for(t, resp), base)) return rc;
@@ -935,6 +935,7 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     };
     fg.pr = pick(fg.NA, t->n2, {3, 4, 5, 6, 8}, 2.0);
     fg.pc = pick(t->n2, t->n1, {2, 3, 4, 6, 8}, 1.5);
+    if (t->fused_c) fg.pr = fusedc_row_outputs(fg.NA, t->n2);
     if (t->sw.fused_pr) { fg.pr = t->sw.fused_pr; fg.pc = t->sw.fused_pc; } // tuning switch PDOG_FUSED_P
     fg.chain_len = chain_len;
     fg.out_ij = d_out_ij;
