@@ -925,6 +925,47 @@ def test_every_roll_instance_pinned(pt, oracle, l):
         bt.close()
 
 
+@pytest.mark.parametrize("l", list(range(29, 102, 4)))
+def test_every_latency_instance_vs_oracle_and_runtime_length_instance(pt, oracle, l):
+    """One compile-time-length instance of the fused and of the tiled kernel per kernel length l = 29 … 101 (lat_inst.hip,
+    lat_lengths.def).  Small batches and a serial chain through each — a window the fused kernel holds in LDS, one it does
+    not (tiled: 4 … 9 sub-windows, rows-of-4 and rows-of-8 row-pass tasks), tiles inside the frame and across its border —
+    positions against the oracle, and positions + bit-identical responses against the runtime-length instance
+    (`pdog_set_tuning "no_fused_c"`)."""
+    import torch
+    from oracle import synth
+    tw = _tw_for_kernel_len(oracle, l)
+    rng = np.random.default_rng(2000 + l)
+    K = oracle.dog_kernel(oracle.sigma(tw), True)
+    h, w = 190, 250
+    for ws, kernel in (((23, 37), 300), ((96, 81), 400)):
+        radii = (ws[0] // 2, ws[1] // 2)
+        n = 2 if kernel == 400 else 6       # (the tiled kernel serves batches of one or two windows)
+        frames, guesses, _ = synth.make_batch(n, h, w, max(2, int(tw)), radii, True, seed=int(rng.integers(1 << 30)), noise=3)
+        fill = oracle.mode_u8(frames[0])
+        d_f, d_g = torch.from_numpy(frames).cuda(), torch.from_numpy(guesses).cuda()
+        res = {}
+        for generic in (0, 1):
+            bt = pt.BatchTracker(h, w, tw, ws, True, fill)
+            bt.set_tuning("no_fused_c", generic)
+            assert bt.kernel_for_batch(n) == kernel, (l, ws, bt.kernel_for_batch(n))
+            got, resp = bt.detect(d_f, d_g, want_resp=True)
+            chain = bt.detect_chain(d_f, (int(guesses[0, 0]), int(guesses[0, 1])))
+            bt.sync()
+            res[generic] = (got.cpu().numpy(), resp.cpu().numpy(), chain.cpu().numpy())
+            bt.close()
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]), (l, ws)
+        for b in range(n):
+            ij, r = oracle.detect(frames[b], fill, K, radii, guesses[b], want_resp=True)
+            assert tuple(int(v) for v in res[0][0][b]) == ij, (l, ws, b)
+            if b == 0:
+                _check_resp(res[0][1][b].T, r, f"latency instance l={l} {ws}")
+        g = (int(guesses[0, 0]), int(guesses[0, 1]))
+        for k in range(n):
+            g = oracle.detect(frames[k], fill, K, radii, g)
+            assert tuple(int(v) for v in res[0][2][k]) == g, (l, ws, k)
+
+
 @pytest.mark.parametrize("win_h", [256, 384, 512, 1024] + [70, 74, 78, 82, 86, 90, 94, 98, 102, 106, 110, 114, 118, 122, 126, 60, 62, 66])
 def test_epilogue_height_classes(pt, oracle, win_h):
     """dog_roll_kernel<65, false, 0, EPI>: instances with statically shortened epilogue bodies, one per window-height class
