@@ -216,6 +216,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
     __shared__ int s_guess[2];
     __shared__ float s_sec[NW];
     __shared__ int s_refine;
+    __shared__ float s_vmax[NW]; // a flagged frame: max |pixel − dc| over the tile, per wave
     __shared__ float s_max, s_sec2;
     __shared__ int s_idx2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -496,13 +497,49 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
                 s_max = pk.best;
                 s_sec2 = pk.second;
                 s_idx2 = pk.idx;
-                if (rf) atomicAdd(g.ex.stat, 1ull);
                 if (!rf && publish)
                     __hip_atomic_store(fg.done_flag, fg.progress ? k + 1 : fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         __syncthreads();
-        if (s_refine) {
+        // A gap within the V = 255 bound.  The bound is proportional to the window's own V = max |pixel − dc| (dog_exact.hpp), and the
+        // tile is still in LDS as exactly those differences: one pass over it (≈0.5 µs, flagged frames only) usually withdraws the
+        // flag — a frame of ±2-level noise has V ≈ 3 — and a refinement that does start knows V (no pass over the pixels in memory).
+        int vknown = -1;
+        bool refine = s_refine != 0;
+        if (refine && g.ex.T < __builtin_huge_valf()) {
+            // (|x| compared as integers: no NaN logic; indices clamped instead of predicated — duplicates do not change a maximum —
+            // so that 16 independent LDS reads are in flight per step)
+            int vbits = 0;
+            for (int r0 = wave; r0 < NA; r0 += 4 * NW)
+                for (int cb = 0; cb < fg.TWin; cb += 256) {
+                    int rd[4][4];
+#pragma unroll
+                    for (int kr = 0; kr < 4; ++kr) {
+                        const int r = min(r0 + kr * NW, NA - 1);
+                        const int *row = reinterpret_cast<const int *>(A + (LT ? fusedc_row_base(r, fg.pitchA) : r * fg.pitchA));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) rd[kr][j] = row[min(cb + lane + 64 * j, fg.TWin - 1)];
+                    }
+#pragma unroll
+                    for (int kr = 0; kr < 4; ++kr)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) vbits = max(vbits, rd[kr][j] & 0x7fffffff);
+                }
+            const float vloc = __builtin_bit_cast(float, vbits);
+            const float vw = wave_max(vloc);
+            if (lane == 0) s_vmax[wave] = vw;
+            __syncthreads();
+            float vm = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) vm = fmaxf(vm, s_vmax[w]);
+            vknown = (int)vm;
+            refine = s_max - s_sec2 <= g.ex.T * (vm * (1.0f / 255.0f)) * 1.00001f;
+            if (!refine && tid == 0 && publish) // withdrawn: the FP32 answer (already written) stands
+                __hip_atomic_store(fg.done_flag, fg.progress ? k + 1 : fg.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (refine) {
+            if (tid == 0) atomicAdd(g.ex.stat, 1ull);
             // A near-tie: the reference's own arithmetic decides (dog_exact.hpp: FP32 rescan → separable Float64 →
             // sequential dense chains for genuine ties).  The tile and RT are not needed any more: their LDS is the scratch.
             // (inlined: as an out-of-line call it made EVERY launch slower — 26 → 46 µs per functor call, the kernel then
@@ -520,6 +557,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
             c.T64 = rp->T64;
             c.T = g.ex.T;
             c.T_rescan = g.ex.T_rescan;
+            c.vmax_known = vknown;
             c.second = s_sec2;
             c.fp32_idx = s_idx2;
             c.cbw = fg.ref_cbw;
