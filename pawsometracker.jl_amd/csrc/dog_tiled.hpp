@@ -42,6 +42,8 @@ struct TiledGeo {
     int *cur;               // [n_clips][2]: the current guess, last arrival → everyone
     unsigned *sync;         // [n_clips][2], zero when a launch starts and when it ends: partial arrivals, frame flag (set after a refined frame only)
     unsigned *abort;        // one word, zero unless a device-side wait of this tracker gave up (wait_counter): every wait polls it
+    unsigned long long *slots; // [n_clips][2][nsub][2]: chains — the sub-windows' partials as two self-validating 64-bit words each (see the frame loop)
+    unsigned tag_base;      // chains: frame k's partials carry the tag tag_base + k + 1; the host advances it by chain_len + 1 per launch
     int fault_inject;       // tests: sub-window 0 of clip 0 never delivers the partial of its second frame (pdog_set_tuning "fault_inject")
 };
 
@@ -259,6 +261,73 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
             if (lane < NW) { pk.best = s_val[lane]; pk.idx = s_idx[lane]; pk.second = s_sec[lane]; }
             peak_wave_reduce(pk, NW);
             int last = 0;
+            // Round 3, clips: ONE memory round trip per frame.  A partial is two 64-bit words that validate themselves — (best | index and
+            // the tag's low byte) and (runner-up | tag), the tag unique per frame and launch — stored by the sub-window's workgroup and
+            // POLLED by every workgroup's wave 0 (a lane per slot) until all of the frame's are there.  No arrival counter, no second
+            // trip to fetch what the counter announced: 11.2 → ≈9.5 µs per 257×257 frame.  Sub-window 0's workgroup plays the part the
+            // last arrival plays for independent windows (writes the answer out, refines, publishes).  Two sets of slots by frame
+            // parity as before: to leave frame k + 1 a workgroup needs everybody's partial of k + 1, so nobody still reads frame k's.
+            Peak w;
+            peak_init(w);
+            bool combined = false;
+            if (tg.chain_len > 1) {
+                unsigned long long *const sl2 = tg.slots + ((size_t)clip * 2 + (k & 1)) * (size_t)nsub * 2;
+                const unsigned tag = tg.tag_base + (unsigned)k + 1u;
+                const bool skip = tg.fault_inject && clip == 0 && s == 0 && k == 1; // (tests: a peer that never delivers)
+                if (lane == 0 && !skip) {
+                    const unsigned long long w0 = (unsigned long long)__builtin_bit_cast(unsigned, pk.best) |
+                                                  ((unsigned long long)((unsigned)pk.idx | ((tag & 0xffu) << 24)) << 32);
+                    const unsigned long long w1 = (unsigned long long)__builtin_bit_cast(unsigned, pk.second) | ((unsigned long long)tag << 32);
+                    __hip_atomic_store(&sl2[2 * s], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&sl2[2 * s + 1], w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                last = (s == 0);
+                if (chain || last) { // (the clip's last frame has no successor: only sub-window 0's workgroup combines it)
+                    constexpr int SPL = TILED_SLOT_CAP / 64; // slots per lane
+                    unsigned long long a[SPL], bq[SPL];
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    int gave_up = 0;
+                    for (unsigned spins = 1;; ++spins) {
+                        bool ok = true;
+#pragma unroll
+                        for (int j = 0; j < SPL; ++j) {
+                            const int q = lane + 64 * j;
+                            a[j] = 0;
+                            bq[j] = 0;
+                            if (q < nsub) {
+                                a[j] = __hip_atomic_load(&sl2[2 * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                bq[j] = __hip_atomic_load(&sl2[2 * q + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                ok = ok && (unsigned)(bq[j] >> 32) == tag && (unsigned)(a[j] >> 56) == (tag & 0xffu);
+                            }
+                        }
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((spins & 63u) == 0u) { // bounded like wait_counter (dog_kernels.hpp): a peer gave up, or 1 s of wall time without the partials
+                            if (__hip_atomic_load(tg.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { gave_up = 1; break; }
+                            if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_TICKS) {
+                                __hip_atomic_store(tg.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (g.ex.range_err) __hip_atomic_store(g.ex.range_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                gave_up = 1;
+                                break;
+                            }
+                        }
+                    }
+                    if (gave_up) {
+                        if (lane == 0) s_abort = 1;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < SPL; ++j) {
+                            const int q = lane + 64 * j;
+                            if (q < nsub) {
+                                const float v = __builtin_bit_cast(float, (unsigned)a[j]);
+                                s_pv[q] = v;
+                                peak_merge(w, v, (int)((unsigned)(a[j] >> 32) & 0xffffffu), __builtin_bit_cast(float, (unsigned)bq[j]));
+                            }
+                        }
+                        combined = true;
+                    }
+                }
+            } else
             if (lane == 0) {
                 __hip_atomic_store(&pv[par + s], pk.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&pi[par + s], pk.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -274,14 +343,13 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
             const int aborted = __shfl(lane == 0 ? s_abort : 0, 0, 64);
             if (lane == 0) { s_last = last; s_refine = 0; }
             if ((last || chain) && !aborted) {
-                Peak w;
-                peak_init(w);
-                for (int sl = lane; sl < nsub; sl += 64) {
-                    const float v = __hip_atomic_load(&pv[par + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (sl < TILED_SLOT_CAP) s_pv[sl] = v;
-                    peak_merge(w, v, __hip_atomic_load(&pi[par + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                               __hip_atomic_load(&ps[par + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                }
+                if (!combined) // independent windows: the last arrival fetches what the counter announced
+                    for (int sl = lane; sl < nsub; sl += 64) {
+                        const float v = __hip_atomic_load(&pv[par + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (sl < TILED_SLOT_CAP) s_pv[sl] = v;
+                        peak_merge(w, v, __hip_atomic_load(&pi[par + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                   __hip_atomic_load(&ps[par + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    }
                 peak_wave_reduce(w);
                 if (lane == 0) {
                     const int x = w.idx / g.n1, y = w.idx - x * g.n1;
@@ -297,7 +365,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
                     if (last) {
                         if (k == 0) range_check(g.ex, g1, g2, hw, g.fh, g.fw);
                         if (k == tg.chain_len - 1) { // nobody looks at the arrival count or the frame flag any more: zero for the next launch
-                            __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (tg.chain_len == 1) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (clips never count arrivals)
                             __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                         if (rf) {

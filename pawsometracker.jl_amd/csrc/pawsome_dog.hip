@@ -297,6 +297,9 @@ struct pdog_tracker {
     bool tiled_c = false;          // the tiled kernel's compile-time-l instance (l = 65) and tile layout
     int *d_tiled_ctl = nullptr;    // [cap][4]: current guess (2), partial arrivals, frame flag
     int tiled_ctl_cap = 0;
+    unsigned long long *d_tiled_slots = nullptr; // [clips][2][nsub][2] tagged partials of the tiled kernel's clips (dog_tiled.hpp)
+    long long tiled_slots_cap = 0; // in slots (clips × sub-windows)
+    unsigned tiled_tag = 0;        // advanced by chain_len + 1 per clip launch: a frame's tag never repeats
     int chain_tmp_cap = 0;
     // two-pass path scratch
     f2 *d_V = nullptr;
@@ -525,7 +528,8 @@ int setup_tiled(pdog_tracker *t)
         ns1 = (t->n1 + sn1 - 1) / sn1;
         ns2 = (t->n2 + sn2 - 1) / sn2;
         need = t->tiled_c ? fusedc_lds_bytes(sn1, sn2, t->L) : fused_lds_bytes(sn1, sn2, t->L);
-        const bool fits = need <= kMaxLds - 1024 && sn2 + t->L - 1 <= 4 * FUSED_NT && (long long)ns1 * ns2 <= (target >= 32 && !user ? 128 : TILED_SLOT_CAP);
+        const bool fits = need <= kMaxLds - 1024 && sn2 + t->L - 1 <= 4 * FUSED_NT && (long long)t->n1 * t->n2 < (1 << 24) && // (a partial's index shares a word with 8 tag bits)
+                          (long long)ns1 * ns2 <= (target >= 32 && !user ? 128 : TILED_SLOT_CAP);
         if (fits) { found = true; break; }
         if (user) break;
     }
@@ -620,6 +624,22 @@ int launch_tiled(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
     tg.sync = reinterpret_cast<unsigned *>(t->d_tiled_ctl + 2 * (size_t)t->tiled_ctl_cap);
     tg.abort = reinterpret_cast<unsigned *>(t->d_tiled_ctl + 4 * (size_t)t->tiled_ctl_cap);
     tg.fault_inject = t->sw.fault_inject ? 1 : 0;
+    tg.slots = nullptr;
+    tg.tag_base = 0;
+    if (chain_len > 1) {
+        if (t->tiled_slots_cap < (long long)n * nsub) {
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            if (t->d_tiled_slots) (void)hipFree(t->d_tiled_slots);
+            t->d_tiled_slots = nullptr; t->tiled_slots_cap = 0;
+            const size_t bytes = sizeof(unsigned long long) * (size_t)n * 2 * nsub * 2;
+            HIP_TRY(hipMalloc(&t->d_tiled_slots, bytes));
+            HIP_TRY(hipMemset(t->d_tiled_slots, 0, bytes)); // tag 0 is never a frame's
+            t->tiled_slots_cap = (long long)n * nsub;
+        }
+        tg.slots = t->d_tiled_slots;
+        tg.tag_base = t->tiled_tag;
+        t->tiled_tag += (unsigned)chain_len + 1u;
+    }
     const void *fn = tiled_kernel_for(t, d_out_resp != nullptr);
     const f2 *tr = t->d_taps_row, *tc = t->d_taps_col;
     if (chain_len > 1) {
@@ -1478,6 +1498,7 @@ int pdog_destroy(pdog_tracker *t)
     if (t->d_dc) (void)hipFree(t->d_dc);
     if (t->d_counter) (void)hipFree(t->d_counter);
     if (t->d_chain_tmp) (void)hipFree(t->d_chain_tmp);
+    if (t->d_tiled_slots) (void)hipFree(t->d_tiled_slots);
     if (t->d_tiled_ctl) (void)hipFree(t->d_tiled_ctl);
     if (t->h2d_stream) { (void)hipStreamSynchronize(t->h2d_stream); (void)hipStreamDestroy(t->h2d_stream); }
     for (int k = 0; k < pdog_tracker::kIngestSlots; ++k) {
