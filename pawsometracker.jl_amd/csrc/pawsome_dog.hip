@@ -519,7 +519,12 @@ int setup_tiled(pdog_tracker *t)
     bool found = false;
     const int user = t->sw.tiled_sub;
     t->tiled_c = fused_has_instance(t->L) && !t->sw.no_fused_c;
-    for (int target : {32, 40, 48, 56, 64, 24, 16}) {
+    // (round 3, with the one-round-trip exchange: 129×129 at 24 → 36 workgroups 8.6–8.8 µs against 9.2–9.7 at 32 → 25; 257×257 at 20 / 24 /
+    // 32: 9.8–10.1 / 10.2 / 10.2–10.5 — kept at 32 so that three clips stay resident; 513×513 at 36 → 225 workgroups 12.2–12.6 against 13.0 at 48)
+    bool small_first = true;
+    for (int target : {24, 32, 40, 48, 56, 64, 24, 16}) {
+        const bool probe24 = small_first && target == 24; // small windows first try 24: only while that keeps the clip at ≤ 48 workgroups
+        small_first = false;
         if (user) target = user;
         ns1 = (t->n1 + target - 1) / target;
         ns2 = (t->n2 + target - 1) / target;
@@ -530,7 +535,7 @@ int setup_tiled(pdog_tracker *t)
         need = t->tiled_c ? fusedc_lds_bytes(sn1, sn2, t->L) : fused_lds_bytes(sn1, sn2, t->L);
         const bool fits = need <= kMaxLds - 1024 && sn2 + t->L - 1 <= 4 * FUSED_NT && (long long)t->n1 * t->n2 < (1 << 24) && // (a partial's index shares a word with 8 tag bits)
                           (long long)ns1 * ns2 <= (target >= 32 && !user ? 128 : TILED_SLOT_CAP);
-        if (fits) { found = true; break; }
+        if (fits && !(probe24 && !user && (long long)ns1 * ns2 > 48)) { found = true; break; }
         if (user) break;
     }
     if (!found) return PDOG_OK;
