@@ -636,7 +636,7 @@ int launch_tiled(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
             HIP_TRY(hipStreamSynchronize(t->stream));
             if (t->d_tiled_slots) (void)hipFree(t->d_tiled_slots);
             t->d_tiled_slots = nullptr; t->tiled_slots_cap = 0;
-            const size_t bytes = sizeof(unsigned long long) * (size_t)n * 2 * nsub * 2;
+            const size_t bytes = sizeof(unsigned long long) * (size_t)n * 3 * nsub * 2; // two partial sets by frame parity + the V set
             HIP_TRY(hipMalloc(&t->d_tiled_slots, bytes));
             HIP_TRY(hipMemset(t->d_tiled_slots, 0, bytes)); // tag 0 is never a frame's
             t->tiled_slots_cap = (long long)n * nsub;
