@@ -16,9 +16,10 @@
 // sub-window borders; indices are the full window's column-major indices, ties → the smallest (findmax, :59).
 //
 // Who combines.  Independent windows (chain_len = 1; an ordinary launch, any number of workgroups): the workgroup whose
-// partial arrives LAST.  Clips (chain_len > 1; a cooperative launch — every workgroup of a clip must be resident,
-// guaranteed or refused): every workgroup waits for the frame's arrival count and combines for itself, see the frame
-// loop.  The arrival count and the frame flag are zero when a launch ends, as they were when it started.
+// partial arrives LAST (an arrival counter; the counter and the frame flag are zero when a launch ends, as they were when it
+// started).  Clips (chain_len > 1; a cooperative launch — every workgroup of a clip must be resident, guaranteed or refused):
+// every workgroup polls the frame's partials — self-validating tagged words, no counter — and combines for itself, see the
+// frame loop; sub-window 0's workgroup writes the answer out, refines and publishes.
 #pragma once
 #include "dog_fused.hpp"
 
@@ -280,10 +281,9 @@ __global__ __launch_bounds__(FUSED_NT) void dog_tiled_kernel(const TiledGeo tg, 
         if (lane == 0) { s_val[wave] = pk.best; s_idx[wave] = pk.idx; s_sec[wave] = pk.second; }
         __syncthreads();
         // ---- this sub-window's partial → memory (two sets of slots, by frame parity: a workgroup can be at most one
-        // frame ahead of the slowest reader).  Independent windows: the LAST arrival combines them.  Chains: EVERY
-        // workgroup waits for the arrival count and combines for itself — the same values in the same order give the same
-        // answer everywhere, two dependent memory round trips per frame instead of four (partials → guess → flag →
-        // guess); only the last arrival writes the answer out, and only a refinement (rare) goes through the frame flag. ----
+        // frame ahead of the slowest reader).  Independent windows: the LAST arrival combines them.  Clips: EVERY
+        // workgroup polls the partials and combines for itself — the same values in the same order give the same answer
+        // everywhere; only sub-window 0's workgroup writes the answer out, and only a refinement (rare) goes through the frame flag. ----
         const bool chain = k + 1 < tg.chain_len; // (the clip's last frame has no successor to wait for: the last arrival alone combines it)
         const int par = (k & 1) * nsub;
         const bool publish = tg.done_flag && clip == 0 && (tg.progress || k == tg.chain_len - 1);
