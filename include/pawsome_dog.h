@@ -135,7 +135,8 @@ int pdog_sync(pdog_tracker *t);
  * tracker's batch kernels, and how many windows have been re-evaluated since the tracker was created (any of the out
  * pointers may be NULL; reading the count drains the stream and reports what its kernels raised, like pdog_sync).
  * pdog_create switches exact mode OFF for windows too tall for the refinement's LDS block (n1 + l beyond ~9000 rows:
- * pdog_set_exact(t, 1) then fails with PDOG_E_ARG); pdog_get_exact tells. */
+ * pdog_set_exact(t, 1) then fails with PDOG_E_ARG); pdog_get_exact tells, and pdog_last_error() holds a note right after that
+ * pdog_create (which still returns PDOG_OK). */
 int pdog_set_exact(pdog_tracker *t, int on);
 /* Pins one of the library's alternative code paths on a live tracker — for tests and same-session A/B, not for a host:
  * the defaults are the measured-best choices.  The library reads NO path switch from the environment (only resource

@@ -1472,6 +1472,8 @@ int pdog_create(int device, int frame_h, int frame_w, double target_width, int w
             CREATE_TRY(hipMemcpy(t->d_rp, &rp, sizeof rp, hipMemcpyHostToDevice));
         }
         t->exact = refine_lds_bytes(t->n1, t->L, 1, 8) <= kMaxLds - 8192;
+        if (!t->exact) // (success all the same: pdog_last_error carries the note, pdog_get_exact reports the state)
+            g_err = "pdog_create: window too tall for the refinement's LDS block (n1 + l beyond ~9000 rows): exact mode is OFF for this tracker";
         if (raise_lds_limit((const void *)dog_finish_kernel, refine_lds_bytes(t->n1, t->L, t->ref_cbw, t->ref_rows))) { pdog_destroy(t); return PDOG_E_HIP; }
     }
 #undef CREATE_TRY
