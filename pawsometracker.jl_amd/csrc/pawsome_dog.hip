@@ -804,7 +804,9 @@ int path_for_batch(const pdog_tracker *t, int n)
     const Variant &v = *t->var;
     if (v.fused) return kPathFused;
     if (t->forced_variant) return v.twopass ? kPathTwoPass : v.id;
-    const bool few = v.twopass ? n <= 256 : (long long)n * (t->nstrips + (t->nthin ? 1 : 0)) < 1000;
+    // (round 3, with the compile-time-l fused instances: 45×45 windows 1024 / 1536 / 2048 per batch: fused 53.8 / 77.3 / 101.9 µs, roll 79.2 / 75.7 / 103.6;
+    // 63×63: 80.9 / 117.5 / 155.8 against 91.6 / 88.7 / 117.2)
+    const bool few = v.twopass ? n <= 256 : (long long)n * (t->nstrips + (t->nthin ? 1 : 0)) < 1200;
     if (t->sw.tiled_force && t->tiled_ok && n <= t->sw.tiled_batch) return kPathTiled; // experiment switch
     if (few && t->fused_ok) return kPathFused;
     if (t->tiled_ok && n <= t->sw.tiled_batch) return kPathTiled; // one or two windows too large for the fused kernel: one launch (dog_tiled.hpp)
