@@ -2063,7 +2063,10 @@ extern "C" int pdog_detect_chains(pdog_tracker *t, const uint8_t *d_frames, int6
     // Enough clips to fill the GPU with one wave per strip → ONE persistent launch (a workgroup per clip walks
     // its frames).  Fewer clips are latency-bound by that single wave per strip; then each frame is a small
     // batch that the two-pass kernels spread over many workgroups (21 µs vs 48 µs per frame, one 45×45 window).
-    const bool persistent = v.roll && v.chain && chain_strips <= 8 &&
+    // (round 3: the fused kernel's compile-time-l instances walk 256 … 4096 clips of 45×45 windows at 27–30 M frames/s, the persistent
+    // roll chain 19–28 M; at 63×63 the chain wins from ≈1400 clips: 23.5 against 18.0 M frames/s at 2048)
+    const bool fused_wins = t->fused_ok && !t->forced_variant && ((long long)t->n1 * t->n2 < 3000 || (long long)n_clips * chain_strips < 1400);
+    const bool persistent = v.roll && v.chain && chain_strips <= 8 && !fused_wins &&
                             (t->forced_variant || !t->small_twopass || (long long)n_clips * chain_strips >= 1000);
     if (t->sw.tiled_force && n_clips == 1 && !t->forced_variant) {
         bool launched = false;
