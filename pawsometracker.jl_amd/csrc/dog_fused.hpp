@@ -222,7 +222,7 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
     __shared__ float s_max, s_sec2;
     __shared__ int s_idx2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
+    int b = blockIdx.x; // this workgroup's window (or clip): b, b + gridDim.x, … — the host launches no more workgroups than stay resident
     const tap_ptr trow = as_taps(taps_row), tcol = as_taps(taps_col);
 
     // tile columns c ≥ TWin and RT columns a ≥ NA are only ever read by the sliding windows of masked outputs: zero once
@@ -234,14 +234,17 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
         for (int x = wave; x < g.n2; x += NW)
             for (int c = NA + lane; c < fg.pitchV; c += 64) Vs[x * fg.pitchV + c] = f2{0.f, 0.f};
     };
-    zero_padding();
-
     // Interior frames of the compile-time-l instances (the whole tile inside the frame — every frame of a clip but those at
     // the border): a thread's addresses relative to the tile's origin never change, so a frame issues its five loads off one
     // uniform base with no per-thread arithmetic, and unpacks with four conversions and a packed subtract per dword.
     constexpr int SU = 4; // rows per thread and batch: the default 45×45 window (109 tile rows, 32 per pass) needs exactly 4
     const int TW4 = (fg.TWin + 3) & ~3;
 
+    // A workgroup walks its windows (clips) one after the other, like the frames of a clip: what a window costs beyond its frames —
+    // workgroup dispatch, the kernel's prologue, the first tap loads — is paid once per workgroup (4096 windows of 45×45:
+    // 12 → ≈9.5 µs per window and CU).
+    for (; b < g.n; b += gridDim.x) {
+    zero_padding(); // (the previous window may have been refined: the refinement uses this LDS as its scratch)
     int g1 = g.guesses[2 * b], g2 = g.guesses[2 * b + 1];
     for (int k = 0; k < fg.chain_len; ++k) {
         const long long fidx = fg.chain_len > 1 ? (long long)b * fg.chain_len + k : (g.frame_index ? g.frame_index[b] : b);
@@ -583,6 +586,8 @@ __global__ __launch_bounds__(FUSED_NT) void dog_fused_kernel(const FusedGeo fg, 
         stamp(3);
         g1 = s_guess[0];   // :167 — the next frame's guess
         g2 = s_guess[1];
+    }
+    __syncthreads(); // (s_guess has been read by everyone before the next window's wave 0 writes it)
     }
 }
 

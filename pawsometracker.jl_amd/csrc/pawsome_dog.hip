@@ -285,6 +285,7 @@ struct pdog_tracker {
     bool forced_variant = false;   // pdog_set_variant pinned the kernel: no batch-size switching
     bool small_twopass = false;    // two-pass kernels are set up and may take over small batches
     bool fused_ok = false;         // the window's tile fits in LDS: the fused kernel takes small batches and short chains
+    int fused_resident = 0;        // workgroups of the fused kernel the device keeps resident (its grid is capped there: a workgroup walks several windows)
     bool fused_c = false;          // … through its compile-time-l instance (dog_fused.hpp: l = 65, the default tracker's), whose tile layout is wider
     int hp_rows = HP_ROWS;         // RT rows (window columns) per column-pass workgroup: 16 (P = 13) or 8 (P = 7)
     int32_t *d_chain_tmp = nullptr; // [2][n_clips][2]: current guesses / step results of multi-clip chains
@@ -806,7 +807,9 @@ int path_for_batch(const pdog_tracker *t, int n)
     if (t->forced_variant) return v.twopass ? kPathTwoPass : v.id;
     // (round 3, with the compile-time-l fused instances: 45×45 windows 1024 / 1536 / 2048 per batch: fused 53.8 / 77.3 / 101.9 µs, roll 79.2 / 75.7 / 103.6;
     // 63×63: 80.9 / 117.5 / 155.8 against 91.6 / 88.7 / 117.2)
-    const bool few = v.twopass ? n <= 256 : (long long)n * (t->nstrips + (t->nthin ? 1 : 0)) < 1200;
+    // (… and since a workgroup of the fused kernel walks several windows — dispatch, prologue and first tap loads once per workgroup — 45×45 windows:
+    // 1024 / 2048 / 4096 per batch 44.5 / 83 / 155 µs against the roll kernel's 79 / 103 / 163: windows below 3000 pixels stay on it at any batch size)
+    const bool few = v.twopass ? n <= 256 : ((long long)n * (t->nstrips + (t->nthin ? 1 : 0)) < 1200 || (long long)t->n1 * t->n2 < 3000);
     if (t->sw.tiled_force && t->tiled_ok && n <= t->sw.tiled_batch) return kPathTiled; // experiment switch
     if (few && t->fused_ok) return kPathFused;
     if (t->tiled_ok && n <= t->sw.tiled_batch) return kPathTiled; // one or two windows too large for the fused kernel: one launch (dog_tiled.hpp)
@@ -1016,7 +1019,13 @@ int launch_fused(pdog_tracker *t, const uint8_t *d_frames, int64_t frame_stride,
         return PDOG_OK;
     }
 #endif
-    hipLaunchKernelGGL(fn, dim3(n), dim3(FUSED_NT), lds, t->stream, fg, (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
+    if (t->fused_resident <= 0) { // once per tracker
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, FUSED_NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) != hipSuccess || cus < 1) cus = 256;
+        t->fused_resident = per_cu * cus;
+    }
+    hipLaunchKernelGGL(fn, dim3(std::min(n, t->fused_resident)), dim3(FUSED_NT), lds, t->stream, fg, (const f2 *)t->d_taps_row, (const f2 *)t->d_taps_col);
     HIP_TRY(hipGetLastError());
     return PDOG_OK;
 }
@@ -1652,6 +1661,7 @@ int pdog_set_tuning(pdog_tracker *t, const char *key, int value)
     else if (k == "fault_inject") t->sw.fault_inject = on;
     else if (k == "no_fused_c") {
         t->sw.no_fused_c = on;
+        t->fused_resident = 0;
         setup_refine_geometry(t); // the tile layout, and with it the refinement's share of the kernel's LDS
         if (t->fused_ok)
             for (bool resp : {false, true})

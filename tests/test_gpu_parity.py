@@ -774,9 +774,13 @@ def test_seeded_fuzz_every_entry_point_vs_oracle(pt, oracle):
 
 def test_kernel_for_batch_reports_the_launch_time_switch(pt):
     bt = pt.BatchTracker(1080, 1920, 25, (45, 45), True, 128)
-    assert bt.info().variant == 100 and bt.kernel_for_batch(1) == 300 and bt.kernel_for_batch(999) == 300 and bt.kernel_for_batch(4096) == 100
+    # windows below 3000 pixels stay on the fused kernel at any batch size (a workgroup walks several windows)
+    assert bt.info().variant == 100 and bt.kernel_for_batch(1) == 300 and bt.kernel_for_batch(999) == 300 and bt.kernel_for_batch(4096) == 300
     bt.set_variant(100)
     assert bt.kernel_for_batch(1) == 100
+    bt.close()
+    bt = pt.BatchTracker(1080, 1920, 25, (63, 63), True, 128)
+    assert bt.kernel_for_batch(1) == 300 and bt.kernel_for_batch(999) == 300 and bt.kernel_for_batch(4096) == 100
     bt.close()
     bt = pt.BatchTracker(1080, 1920, 25, (256, 256), True, 128)
     # one or two windows too large for the fused kernel: the tiled kernel (a workgroup per sub-window, one launch)
